@@ -1,0 +1,132 @@
+"""The CPU oracle (oracle/rt_oracle.c) against the golden vectors produced by the REAL
+reference (oracle/_ref/ref_harness, see tests/golden/make_golden.py).  Bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, asset
+
+MESHES = ["TorusKnot", "BlenderMonkey", "unitychan"]
+_scenes = {}
+
+
+def scene_for(O, name):
+    if name not in _scenes:
+        s = O.Scene()
+        sh = s.add_mesh_obj(asset(name + ".obj"))
+        _scenes[name] = (s, sh)
+    return _scenes[name]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_parser_and_tree_match_reference(oracle_mod, name):
+    g = np.load(os.path.join(GOLDEN, "mesh_%s.npz" % name))
+    s, sh = scene_for(oracle_mod, name)
+    c = s.counts(sh)
+    assert [c["points"], c["texcoords"], c["normals"], c["tris"]] == g["counts"][:4].tolist()
+    assert c["nodes"] == g["counts"][5] == 2 * c["tris"] - 1
+    a = s.mesh_arrays(sh)
+    for k in ("points", "texcoords", "normals"):
+        assert (bits(a[k]) == bits(g[k])).all(), k
+    for k in ("pidx", "tidx", "nidx", "matid"):
+        assert (a[k] == g[k]).all(), k
+    b, t = s.tree_preorder(sh)
+    assert (bits(b) == bits(g["tree_bounds"])).all()
+    assert (t == g["tree_tri"]).all()
+    assert (bits(s.shape_bounds(sh)) == bits(g["shape_bounds"])).all()
+
+
+def test_topology_facts_from_survey(oracle_mod):
+    # nodes 2399/1935/32111; material ids -1 / 0 / 0..8
+    expect = {"TorusKnot": (2399, -1, -1), "BlenderMonkey": (1935, 0, 0), "unitychan": (32111, 0, 8)}
+    for name, (nodes, lo, hi) in expect.items():
+        s, sh = scene_for(oracle_mod, name)
+        assert s.counts(sh)["nodes"] == nodes
+        m = s.mesh_arrays(sh)["matid"]
+        assert (m.min(), m.max()) == (lo, hi)
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_closest_hit_matches_reference(oracle_mod, name):
+    g = np.load(os.path.join(GOLDEN, "closest_%s.npz" % name))
+    s, sh = scene_for(oracle_mod, name)
+    hf, hs, ht = s.trace_closest(g["rays"])
+    assert (hs == g["shape"]).all()
+    hit = hs >= 0
+    assert hit.sum() > 100
+    assert (ht[hit] == g["tri"][hit]).all()
+    assert (bits(hf[hit]) == bits(g["hit"][hit])).all()
+
+
+@pytest.mark.parametrize("mat", [0, 4])
+def test_texture_sample_matches_reference(oracle_mod, mat):
+    g = np.load(os.path.join(GOLDEN, "texsample_unitychan_m%d.npz" % mat))
+    s, sh = scene_for(oracle_mod, "unitychan")
+    out = s.texture_sample(sh, mat, g["uv"])
+    assert (bits(out) == bits(g["rgba"])).all()
+
+
+FRAMES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "frame_*.npz")))
+
+
+@pytest.mark.parametrize("tag", FRAMES)
+def test_frame_matches_reference(oracle_mod, tag):
+    O = oracle_mod
+    g = np.load(os.path.join(GOLDEN, "frame_%s.npz" % tag))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    s = O.Scene()
+    sh = s.add_mesh_obj(asset(str(g["mesh"]) + ".obj"))
+    s.set_material(sh, g["material"])
+    fb = O.Framebuffer(W, H)
+    for p in range(pass0, pass0 + npass):
+        s.render_range(fb, 0, W * H - 1, depth, bool(preview), p, ns, seed)
+    accum, argb = fb.read()
+    assert (argb == g["argb"]).all()
+    if not preview:
+        assert (bits(accum) == bits(g["accum"])).all()
+
+
+@pytest.mark.parametrize("tag", ["unitychan_diffuse", "monkey_blendfuzz"])
+def test_ray_trace_matches_reference(oracle_mod, tag):
+    O = oracle_mod
+    g = np.load(os.path.join(GOLDEN, "raytrace_%s.npz" % tag))
+    depth, seed, W, H = [int(v) for v in g["params"]]
+    s = O.Scene()
+    sh = s.add_mesh_obj(asset(str(g["mesh"]) + ".obj"))
+    s.set_material(sh, g["material"])
+    rgb = s.ray_trace(g["rays"], g["keys"], depth, False, seed, W, H)
+    assert (bits(rgb) == bits(g["rgb"])).all()
+
+
+def test_f64_unit_vector_mode_is_close_to_libm(oracle_mod):
+    """The device evaluates the fuzzy-reflection direction with double transcendentals
+    (ORC_UNITVEC_F64); it must stay within a few ulp of the reference's libm floats."""
+    O = oracle_mod
+    g = np.load(os.path.join(GOLDEN, "frame_torus_blendfuzz_d6.npz"))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    s = O.Scene()
+    sh = s.add_mesh_obj(asset("TorusKnot.obj"))
+    s.set_material(sh, g["material"])
+    s.set_unitvec_mode(O.UNITVEC_F64)
+    fb = O.Framebuffer(W, H)
+    s.render_range(fb, 0, W * H - 1, depth, False, pass0, ns, seed)
+    accum, _ = fb.read()
+    d = np.abs(accum[:, :3] - g["accum"][:, :3]).max(axis=1)
+    assert (d <= 1e-4).mean() > 0.995
+
+
+def test_pool_equals_serial(oracle_mod):
+    O = oracle_mod
+    s, sh = scene_for(O, "TorusKnot")
+    s.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+    a, b = O.Framebuffer(80, 45), O.Framebuffer(80, 45)
+    s.render_range(a, 0, 80 * 45 - 1, 4, False, 0, 4, 11)
+    s.render_pass_pool(b, 4, False, 0, 4, 11, threads=4, task_rows=10)
+    (aa, ab), (ba, bb) = a.read(), b.read()
+    assert (bits(aa) == bits(ba)).all() and (ab == bb).all()
