@@ -1,0 +1,178 @@
+/*
+ * rtwin.h -- C ABI of the MI355X-native ray-trace hot path (librtwin.so).
+ *
+ * The reference (aosyang/RayTracerWin) has no FFI: its hot path is reached only through
+ * in-process C++ calls.  The narrowest seam is the pixel-range task call
+ *     void ThreadWorker_Render(int begin, int end, int MaxBounceCount, const RenderOption&)
+ * (Src/RayTracerProgram.cpp:131), fed by a scene built with
+ *     RayTracerScene::AddShape(RMeshShape::Create(path), material)   (Src/RayTracerScene.cpp:25)
+ * and drained through the global accuBuffer[] / bitcolor[] arrays (Src/RayTracerProgram.cpp:49,77).
+ * Every entry point below names the reference interface it replaces.  Plain pointers and
+ * sizes only; all device memory is owned by the library behind opaque handles (or wrapped
+ * from the caller via rtw_framebuffer_wrap).  Every function returns RTW_OK (0) or a
+ * negative rtw_status; rtw_last_error() gives the message for the calling thread.
+ *
+ * There is no CPU fallback: without a HIP device every device entry point fails with
+ * RTW_ERR_NO_DEVICE.
+ */
+#ifndef RTWIN_H
+#define RTWIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RTW_OK = 0,
+    RTW_ERR_INVALID = -1,       /* bad argument / handle */
+    RTW_ERR_NO_DEVICE = -2,     /* no usable HIP device */
+    RTW_ERR_HIP = -3,           /* a HIP runtime call failed */
+    RTW_ERR_IO = -4,            /* file could not be read / written */
+    RTW_ERR_STATE = -5,         /* scene not committed, etc. */
+    RTW_ERR_LIMIT = -6          /* exceeds a compiled-in limit (RTW_MAX_*) */
+} rtw_status;
+
+#define RTW_MAX_BOUNCE 16          /* deepest MaxBounceTimes the device path stack holds */
+#define RTW_MAX_MATERIAL_NODES 64
+#define RTW_MAX_MESH_MATERIALS 64  /* distinct usemtl names per mesh */
+#define RTW_UNIT_TABLE_SIZE 0xFFFFFFu   /* MaxUnitVectorNums, Src/Math.cpp:17 */
+
+/* Flattened ISurfaceMaterial tree (Src/SurfaceMaterials.h:47-141); root is node 0 and
+ * children always have larger indices than their parent. */
+typedef enum {
+    RTW_MAT_DIFFUSE = 0,          /* SurfaceMaterial_Diffuse(albedo)                      */
+    RTW_MAT_DIFFUSE_CHECKER = 1,  /* SurfaceMaterial_DiffuseChecker(albedo, param=size)   */
+    RTW_MAT_REFLECTIVE = 2,       /* SurfaceMaterial_Reflective(albedo, param=fuzziness)  */
+    RTW_MAT_EMISSIVE = 3,         /* SurfaceMaterial_Emissive(colour)                     */
+    RTW_MAT_BLEND = 4,            /* SurfaceMaterial_Blend(A, B, param=factor)            */
+    RTW_MAT_COMBINE = 5,          /* SurfaceMaterial_Combine(A, B)                        */
+    RTW_MAT_NULL = 6              /* SurfaceMaterial_Null                                 */
+} rtw_material_type;
+
+typedef struct {
+    int32_t type;
+    float r, g, b;
+    float param;
+    int32_t child_a, child_b;
+    int32_t pad;
+} rtw_material_node;              /* 32 bytes */
+
+typedef struct {
+    uint64_t rays;          /* FindIntersectionWithScene-equivalent queries            */
+    uint64_t box_tests;     /* node / shape box tests actually executed                */
+    uint64_t tri_tests;     /* triangle tests executed                                 */
+    uint64_t shaded_hits;   /* hits that ran the shading-input block                   */
+    uint64_t tex_samples;   /* bilinear texture samples                                */
+    uint64_t camera_rays;
+} rtw_stats;
+
+typedef struct rtw_context rtw_context;
+typedef struct rtw_scene rtw_scene;
+typedef struct rtw_framebuffer rtw_framebuffer;
+
+/* ---- context: one per (process, GPU).  Replaces the process-global state of
+ * RayTracerProgram::Run (Src/RayTracerProgram.cpp:437-443: srand + the unit-vector table
+ * of RMath::InitPseudoRandomUnitVector, Src/Math.cpp:24-31). ---- */
+int rtw_context_create(int device_index, rtw_context** out);
+int rtw_context_destroy(rtw_context* ctx);
+/* run every later launch of this context on the caller's hipStream_t (e.g. torch's) */
+int rtw_context_set_stream(rtw_context* ctx, void* hip_stream);
+int rtw_context_synchronize(rtw_context* ctx);
+const char* rtw_last_error(void);
+const char* rtw_version(void);
+
+/* ---- scene: RayTracerScene (Src/RayTracerScene.h:43-62) ---- */
+int rtw_scene_create(rtw_context* ctx, rtw_scene** out);
+int rtw_scene_destroy(rtw_scene* scene);
+/* RayTracerScene::AddShape(RMeshShape::Create(path), ...) : OBJ + sibling MTL + PNG
+ * textures with the reference's parser semantics (Src/MeshShape.cpp:65-278). */
+int rtw_scene_add_mesh_obj(rtw_scene* scene, const char* obj_path, int* out_shape);
+/* Same, from arrays the caller already holds (the members of RMeshShape,
+ * Src/MeshShape.h:25-37).  positions/texcoords/normals are 3 floats per element,
+ * idx_* are 3 ints per triangle (0-based), tri_material is 1 int per triangle (-1 = none).
+ * shape_bounds6 may be NULL (then the bounds of all positions, Src/MeshShape.cpp:109). */
+int rtw_scene_add_mesh(rtw_scene* scene,
+                       const float* positions, int n_positions,
+                       const float* texcoords, int n_texcoords,
+                       const float* normals, int n_normals,
+                       const int32_t* idx_p, const int32_t* idx_t, const int32_t* idx_n,
+                       const int32_t* tri_material, int n_tris,
+                       const float* shape_bounds6, int* out_shape);
+/* RTexture::LoadTexturePNG result for one material id (Src/Texture.cpp:119-151):
+ * 8-bit texels, channels 3 (RGB, alpha = 1) or 4 (RGBA), row-major, top row first. */
+int rtw_scene_set_texture(rtw_scene* scene, int shape, int material_id,
+                          const uint8_t* texels, int width, int height, int channels);
+/* RShape::SetSurfaceMaterial (Src/Shapes.cpp:9) */
+int rtw_scene_set_material(rtw_scene* scene, int shape, const rtw_material_node* nodes, int n_nodes);
+/* build + flatten + upload; the scene is immutable afterwards (all reference queries are const) */
+int rtw_scene_commit(rtw_scene* scene);
+/* info[0..7] = points, texcoords, normals, triangles, materials, nodes, textures, max tree depth */
+int rtw_scene_mesh_info(const rtw_scene* scene, int shape, int32_t info[8], float shape_bounds6[6]);
+/* flattened tree for inspection: per node 6 floats (min, max), skip index, triangle (-1 internal) */
+int rtw_scene_mesh_nodes(const rtw_scene* scene, int shape, float* bounds6, int32_t* skip, int32_t* tri, int max_nodes);
+/* traversal pruning (result-preserving segment clip); default on */
+int rtw_scene_set_prune(rtw_scene* scene, int enabled);
+
+/* ---- ray-level queries (parity surface) ---- */
+/* RayTracerScene::FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) for n rays.
+ * rays: 7 floats each (origin, direction, distance).  hits: 11 floats each (HitPosition,
+ * HitNormal, Distance, SampledColor, SampledAlpha); shape/tri: hit shape index (-1 miss)
+ * and original triangle index.  Host buffers. */
+int rtw_trace_closest(rtw_scene* scene, const float* rays, int64_t n,
+                      float* hits11, int32_t* shape, int32_t* tri);
+/* RayTracerScene::RayTrace (Src/RayTracerScene.cpp:31-97) for n explicit rays; keys2 holds
+ * (pixel, sample) per ray, which select the random stream.  rgb: 3 floats each. */
+int rtw_ray_trace(rtw_scene* scene, const float* rays, const uint32_t* keys2, int64_t n,
+                  int max_bounce, int use_base_color, uint32_t seed, int width, int height, float* rgb);
+/* RTexture::Sample (Src/Texture.cpp:23-57) probes: uv 2 floats each -> rgba 4 floats each */
+int rtw_texture_sample(rtw_scene* scene, int shape, int material_id, const float* uv, int64_t n, float* rgba);
+
+/* ---- framebuffer: accuBuffer[] + bitcolor[] (Src/RayTracerProgram.cpp:49-77) ---- */
+int rtw_framebuffer_create(rtw_context* ctx, int width, int height, rtw_framebuffer** out);
+/* wrap caller-owned device memory: accum = width*height*16 bytes (sum.xyz, int count),
+ * argb = width*height*4 bytes.  Lets torch own the buffers that RCCL gathers. */
+int rtw_framebuffer_wrap(rtw_context* ctx, int width, int height, void* accum_dev, void* argb_dev, rtw_framebuffer** out);
+int rtw_framebuffer_destroy(rtw_framebuffer* fb);
+int rtw_framebuffer_clear(rtw_framebuffer* fb);
+/* copy out: accum4 = width*height*4 floats (sum.xyz, count as float); argb = 0xAARRGGBB */
+int rtw_framebuffer_read_float(rtw_framebuffer* fb, float* accum4);
+int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb);
+
+/* ---- the hot path ---- */
+/* ThreadWorker_Render(begin, end, MaxBounceCount, RenderOption{use_base_color})
+ * (Src/RayTracerProgram.cpp:131-188) for one pass: pixel indices begin..end INCLUSIVE,
+ * row-major.  sub_samples in 1..4 (the reference always uses 4); pass_index and seed
+ * select the random streams.  Asynchronous on the context's stream; calls on disjoint
+ * ranges may be issued back to back. */
+int rtw_render_range(rtw_scene* scene, rtw_framebuffer* fb, int begin, int end, int max_bounce,
+                     int use_base_color, int pass_index, int sub_samples, uint32_t seed);
+/* One pass over this rank's share of the frame: the reference's NumTaskRows-row tasks
+ * (Src/RayTracerProgram.cpp:282,294-301) dealt round-robin, task t belongs to rank
+ * t % world.  Pixels keep their global indices (and random streams), so the image is
+ * identical for every world size. */
+int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
+                     int max_bounce, int use_base_color, int pass_index, int sub_samples, uint32_t seed);
+
+/* work counters of launches since the last reset (only counted while enabled) */
+int rtw_stats_enable(rtw_context* ctx, int enabled);
+int rtw_stats_reset(rtw_context* ctx);
+int rtw_stats_get(rtw_context* ctx, rtw_stats* out);
+
+/* tables the device uses, for pinning against the oracle */
+uint32_t rtw_rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);
+int rtw_unit_table_entry(uint32_t index, float out3[3]);
+int rtw_gamma_thresholds(float out256[256]);
+int rtw_texel_lut(float out256[256]);
+
+/* ---- host-side file helpers: RTexture::LoadTexturePNG / SaveBufferToPNG
+ * (Src/Texture.cpp:59-199, 201-283) ---- */
+int rtw_png_load(const char* path, uint8_t** texels_out, int* width, int* height, int* channels);
+void rtw_png_free(uint8_t* texels);
+int rtw_png_save_argb(const char* path, const uint32_t* argb, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTWIN_H */

@@ -234,5 +234,13 @@ def texel_lut():
     return o
 
 
+def make_pixel_colors(rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+    out = np.zeros(len(rgb), np.uint32)
+    lib().orc_make_pixel_colors.restype = None
+    lib().orc_make_pixel_colors(_p(rgb), C.c_int64(len(rgb)), _p(out))
+    return out
+
+
 def hw_threads():
     return int(lib().orc_hw_threads())

@@ -1193,3 +1193,9 @@ int orc_ray_trace(const orc_scene* sc, const float* rays, const uint32_t* keys2,
     }
     return 0;
 }
+
+/* MakePixelColor(LinearToGamma(c)) for n colours (3 floats each): Src/ColorBuffer.h:81-109 */
+void orc_make_pixel_colors(const float* rgb, int64_t n, uint32_t* out)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = make_pixel_color(linear_to_gamma(v3(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2])));
+}

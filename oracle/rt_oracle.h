@@ -113,6 +113,7 @@ void orc_unit_table_entry(uint32_t index, float out3[3]);
 void orc_gamma_thresholds(float out256[256]);
 void orc_texel_lut(float out256[256]);
 int orc_hw_threads(void);
+void orc_make_pixel_colors(const float* rgb, int64_t n, uint32_t* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,445 @@
+"""ctypes binding of librtwin.so + the host-side mirror of the reference interface."""
+import atexit
+import ctypes as C
+import os
+import subprocess
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "librtwin.so")
+
+MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("r", "<f4"), ("g", "<f4"), ("b", "<f4"), ("param", "<f4"),
+                           ("child_a", "<i4"), ("child_b", "<i4"), ("pad", "<i4")])
+MAT_DIFFUSE, MAT_DIFFUSE_CHECKER, MAT_REFLECTIVE, MAT_EMISSIVE, MAT_BLEND, MAT_COMBINE, MAT_NULL = range(7)
+
+
+class RtwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librtwin error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "box_tests", "tri_tests", "shaded_hits", "tex_samples", "camera_rays")]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False, extra=""):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if extra:
+        cmd.append("EXTRA=" + extra)
+    if force:
+        subprocess.check_call(cmd + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def library():
+    """Load librtwin.so; fails loudly when the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError("raytracerwin_amd: %s is missing -- run __graft_entry__.build() "
+                              "(there is no CPU fallback)" % _LIB)
+        L = C.CDLL(_LIB)
+        L.rtw_last_error.restype = C.c_char_p
+        L.rtw_version.restype = C.c_char_p
+        L.rtw_rand31.restype = C.c_uint32
+        L.rtw_png_free.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise RtwError(rc, library().rtw_last_error().decode())
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------------------------------------
+# materials: same constructors as Src/SurfaceMaterials.h, flattened to rtw_material_node[]
+# ---------------------------------------------------------------------------------------------
+class ISurfaceMaterial:
+    def _flatten(self, out):
+        raise NotImplementedError
+
+    def nodes(self):
+        out = []
+        self._flatten(out)
+        arr = np.zeros(len(out), dtype=MATERIAL_DTYPE)
+        for i, n in enumerate(out):
+            arr[i] = n
+        return arr
+
+
+class _Leaf(ISurfaceMaterial):
+    TYPE = None
+
+    def __init__(self, rgb=(1.0, 1.0, 1.0), param=0.0):
+        self.rgb, self.param = tuple(float(v) for v in rgb), float(param)
+
+    def _flatten(self, out):
+        out.append((self.TYPE, self.rgb[0], self.rgb[1], self.rgb[2], self.param, 0, 0, 0))
+        return len(out) - 1
+
+
+class SurfaceMaterial_Diffuse(_Leaf):
+    TYPE = MAT_DIFFUSE
+
+    def __init__(self, InAlbedo=(1.0, 1.0, 1.0)):
+        super().__init__(InAlbedo)
+
+
+class SurfaceMaterial_DiffuseChecker(_Leaf):
+    TYPE = MAT_DIFFUSE_CHECKER
+
+    def __init__(self, InAlbedo=(1.0, 1.0, 1.0), InPatternSize=5.0):
+        super().__init__(InAlbedo, InPatternSize)
+
+
+class SurfaceMaterial_Reflective(_Leaf):
+    TYPE = MAT_REFLECTIVE
+
+    def __init__(self, InAlbedo=(1.0, 1.0, 1.0), InFuzziness=0.0):
+        super().__init__(InAlbedo, InFuzziness)
+
+
+class SurfaceMaterial_Emissive(_Leaf):
+    TYPE = MAT_EMISSIVE
+
+    def __init__(self, InColor):
+        super().__init__(InColor)
+
+
+class SurfaceMaterial_Null(_Leaf):
+    TYPE = MAT_NULL
+
+    def __init__(self):
+        super().__init__((0.0, 0.0, 0.0))
+
+
+class _Pair(ISurfaceMaterial):
+    TYPE = None
+
+    def __init__(self, a, b, param=0.0):
+        self.a, self.b, self.param = a, b, float(param)
+
+    def _flatten(self, out):
+        me = len(out)
+        out.append(None)
+        ia = self.a._flatten(out)
+        ib = self.b._flatten(out)
+        out[me] = (self.TYPE, 0.0, 0.0, 0.0, self.param, ia, ib, 0)
+        return me
+
+
+class SurfaceMaterial_Blend(_Pair):
+    TYPE = MAT_BLEND
+
+    def __init__(self, InMaterialA, InMaterialB, InBlendFactor):
+        super().__init__(InMaterialA, InMaterialB, InBlendFactor)
+
+
+class SurfaceMaterial_Combine(_Pair):
+    TYPE = MAT_COMBINE
+
+    def __init__(self, InMaterialA, InMaterialB):
+        super().__init__(InMaterialA, InMaterialB)
+
+
+class _RawMaterial(ISurfaceMaterial):
+    def __init__(self, arr):
+        self.arr = np.ascontiguousarray(arr, dtype=MATERIAL_DTYPE)
+
+    def nodes(self):
+        return self.arr
+
+
+def material_nodes_from_array(arr):
+    return _RawMaterial(arr)
+
+
+class RenderOption:
+    """Src/RayTracerScene.h:27-35"""
+
+    def __init__(self, UseBaseColor=False):
+        self.UseBaseColor = bool(UseBaseColor)
+
+
+class RMeshShape:
+    """RMeshShape::Create(path) (Src/MeshShape.h:23): a deferred description; the OBJ is
+    parsed by the library when the shape is added to a scene."""
+
+    def __init__(self, Filename=None, arrays=None):
+        self.Filename, self.arrays = Filename, arrays
+
+    @staticmethod
+    def Create(Filename):
+        return RMeshShape(Filename=Filename)
+
+    @staticmethod
+    def FromArrays(points, texcoords, normals, pidx, tidx, nidx, matid=None, bounds=None, textures=None):
+        return RMeshShape(arrays=dict(points=points, texcoords=texcoords, normals=normals, pidx=pidx, tidx=tidx,
+                                      nidx=nidx, matid=matid, bounds=bounds, textures=textures or {}))
+
+
+# ---------------------------------------------------------------------------------------------
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all_contexts():
+    # release device objects while the HIP runtime is still alive (not from __del__ at interpreter teardown)
+    for c in list(_live_contexts):
+        c.close()
+
+
+class Context:
+    """One per (process, GPU): stream + the device tables shared by every scene."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        self._children = weakref.WeakSet()      # scenes / framebuffers: destroyed before the context
+        _check(library().rtw_context_create(int(device), C.byref(self.h)))
+        self.device = device
+        _live_contexts.add(self)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, hip_stream):
+        _check(library().rtw_context_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
+    def synchronize(self):
+        _check(library().rtw_context_synchronize(self.h))
+
+    def stats_enable(self, on=True):
+        _check(library().rtw_stats_enable(self.h, int(on)))
+
+    def stats_reset(self):
+        _check(library().rtw_stats_reset(self.h))
+
+    def stats(self):
+        s = Stats()
+        _check(library().rtw_stats_get(self.h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in Stats._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            for child in list(self._children):
+                child.close()
+            library().rtw_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Framebuffer:
+    """accuBuffer[] + bitcolor[] (Src/RayTracerProgram.cpp:49-77) on the device."""
+
+    def __init__(self, ctx, width, height, accum_ptr=None, argb_ptr=None):
+        self.ctx, self.width, self.height = ctx, int(width), int(height)
+        self.h = C.c_void_p()
+        ctx._children.add(self)
+        if accum_ptr is None:
+            _check(library().rtw_framebuffer_create(ctx.h, self.width, self.height, C.byref(self.h)))
+        else:
+            _check(library().rtw_framebuffer_wrap(ctx.h, self.width, self.height, C.c_void_p(int(accum_ptr)),
+                                                  C.c_void_p(int(argb_ptr)), C.byref(self.h)))
+
+    def clear(self):
+        _check(library().rtw_framebuffer_clear(self.h))
+
+    def read_float(self):
+        out = np.empty((self.width * self.height, 4), np.float32)
+        _check(library().rtw_framebuffer_read_float(self.h, _p(out)))
+        return out
+
+    def resolve_argb(self):
+        out = np.empty(self.width * self.height, np.uint32)
+        _check(library().rtw_framebuffer_resolve_argb(self.h, _p(out)))
+        return out
+
+    def save_png(self, path):
+        argb = self.resolve_argb()
+        _check(library().rtw_png_save_argb(path.encode(), _p(argb), self.width, self.height))
+
+    def close(self):
+        if getattr(self, "h", None):
+            library().rtw_framebuffer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RayTracerScene:
+    """Src/RayTracerScene.h:43-62.  AddShape() collects shapes; the first query commits."""
+
+    def __init__(self, ctx):
+        # ctx=None gives a host-only scene (parse / build / inspect); device queries then raise
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        if ctx is not None:
+            ctx._children.add(self)
+        _check(library().rtw_scene_create(ctx.h if ctx is not None else None, C.byref(self.h)))
+        self.committed = False
+        self.n_shapes = 0
+
+    def AddShape(self, Shape, SurfaceMaterial=None):
+        L = library()
+        idx = C.c_int(-1)
+        if Shape.Filename is not None:
+            _check(L.rtw_scene_add_mesh_obj(self.h, Shape.Filename.encode(), C.byref(idx)))
+        else:
+            a = Shape.arrays
+            f = lambda k: np.ascontiguousarray(a[k], np.float32).reshape(-1, 3)  # noqa: E731
+            i = lambda k: np.ascontiguousarray(a[k], np.int32).reshape(-1, 3)  # noqa: E731
+            pts, tcs, nrm, pi, ti, ni = f("points"), f("texcoords"), f("normals"), i("pidx"), i("tidx"), i("nidx")
+            mat = None if a["matid"] is None else np.ascontiguousarray(a["matid"], np.int32)
+            bnd = None if a["bounds"] is None else np.ascontiguousarray(a["bounds"], np.float32)
+            _check(L.rtw_scene_add_mesh(self.h, _p(pts), len(pts), _p(tcs), len(tcs), _p(nrm), len(nrm), _p(pi), _p(ti),
+                                        _p(ni), None if mat is None else _p(mat), len(pi),
+                                        None if bnd is None else _p(bnd), C.byref(idx)))
+            for mid, px in a["textures"].items():
+                px = np.ascontiguousarray(px, np.uint8)
+                h, w, c = px.shape
+                _check(L.rtw_scene_set_texture(self.h, idx.value, int(mid), _p(px), w, h, c))
+        if SurfaceMaterial is not None:
+            nodes = SurfaceMaterial.nodes()
+            _check(L.rtw_scene_set_material(self.h, idx.value, _p(nodes), len(nodes)))
+        self.n_shapes += 1
+        return idx.value
+
+    def set_prune(self, enabled):
+        _check(library().rtw_scene_set_prune(self.h, int(enabled)))
+
+    def commit(self):
+        if not self.committed:
+            _check(library().rtw_scene_commit(self.h))
+            self.committed = True
+
+    def mesh_info(self, shape=0):
+        info = np.zeros(8, np.int32)
+        b = np.zeros(6, np.float32)
+        _check(library().rtw_scene_mesh_info(self.h, shape, _p(info), _p(b)))
+        keys = ("points", "texcoords", "normals", "tris", "materials", "nodes", "textures", "max_depth")
+        d = {k: int(v) for k, v in zip(keys, info)}
+        d["bounds"] = b
+        return d
+
+    def mesh_nodes(self, shape=0):
+        self.commit()
+        n = self.mesh_info(shape)["nodes"]
+        b = np.zeros((n, 6), np.float32)
+        s = np.zeros(n, np.int32)
+        t = np.zeros(n, np.int32)
+        _check(library().rtw_scene_mesh_nodes(self.h, shape, _p(b), _p(s), _p(t), n))
+        return b, s, t
+
+    def FindIntersectionWithScene(self, rays):
+        """rays: (n,7) origin, direction, distance -> (hits (n,11), shape (n,), triangle (n,))"""
+        self.commit()
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 7)
+        n = len(rays)
+        hits = np.zeros((n, 11), np.float32)
+        shape = np.zeros(n, np.int32)
+        tri = np.zeros(n, np.int32)
+        _check(library().rtw_trace_closest(self.h, _p(rays), C.c_int64(n), _p(hits), _p(shape), _p(tri)))
+        return hits, shape, tri
+
+    def RayTrace(self, rays, keys, MaxBounceTimes, InOption=None, seed=12345, width=1920, height=1080):
+        self.commit()
+        opt = InOption or RenderOption()
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 7)
+        keys = np.ascontiguousarray(keys, np.uint32).reshape(-1, 2)
+        out = np.zeros((len(rays), 3), np.float32)
+        _check(library().rtw_ray_trace(self.h, _p(rays), _p(keys), C.c_int64(len(rays)), int(MaxBounceTimes),
+                                       int(opt.UseBaseColor), C.c_uint32(seed), int(width), int(height), _p(out)))
+        return out
+
+    def texture_sample(self, shape, material_id, uv):
+        self.commit()
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 4), np.float32)
+        _check(library().rtw_texture_sample(self.h, shape, material_id, _p(uv), C.c_int64(len(uv)), _p(out)))
+        return out
+
+    def render_tasks(self, fb, task_rows, rank, world, MaxBounceCount, InOption=None, pass_index=0, sub_samples=4,
+                     seed=12345):
+        self.commit()
+        opt = InOption or RenderOption()
+        _check(library().rtw_render_tasks(self.h, fb.h, int(task_rows), int(rank), int(world), int(MaxBounceCount),
+                                          int(opt.UseBaseColor), int(pass_index), int(sub_samples), C.c_uint32(seed)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            library().rtw_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ThreadWorker_Render(scene, fb, begin, end, MaxBounceCount, InOption=None, pass_index=0, sub_samples=4, seed=12345):
+    """void ThreadWorker_Render(int begin, int end, int MaxBounceCount, const RenderOption&)
+    (Src/RayTracerProgram.cpp:131): the scene and buffers the reference reaches through globals
+    are explicit here; begin..end are inclusive linear pixel indices.  Asynchronous."""
+    scene.commit()
+    opt = InOption or RenderOption()
+    _check(library().rtw_render_range(scene.h, fb.h, int(begin), int(end), int(MaxBounceCount), int(opt.UseBaseColor),
+                                      int(pass_index), int(sub_samples), C.c_uint32(seed)))
+
+
+def rand31(seed, pixel, sample, counter):
+    return int(library().rtw_rand31(C.c_uint32(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(counter)))
+
+
+def unit_table_entry(i):
+    o = np.zeros(3, np.float32)
+    _check(library().rtw_unit_table_entry(C.c_uint32(i), _p(o)))
+    return o
+
+
+def gamma_thresholds():
+    o = np.zeros(256, np.float32)
+    _check(library().rtw_gamma_thresholds(_p(o)))
+    return o
+
+
+def texel_lut():
+    o = np.zeros(256, np.float32)
+    _check(library().rtw_texel_lut(_p(o)))
+    return o
+
+
+def png_load(path):
+    px = C.POINTER(C.c_uint8)()
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    _check(library().rtw_png_load(path.encode(), C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, c.value)).copy()
+    finally:
+        library().rtw_png_free(px)

@@ -1,0 +1,24 @@
+// rtw_device.h -- launch wrappers implemented in rtw_device.hip (internal).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "rtw_types.h"
+
+#define RTW_MAX_BOUNCE_DEV 16
+
+namespace rtw {
+
+// bytes of level workspace a launch of `work_items` threads needs (rounded up to whole 256-thread blocks)
+inline size_t level_workspace_bytes(long long work_items, int max_bounce)
+{
+    const size_t threads = (size_t)((work_items + 255) / 256) * 256;
+    return threads * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
+}
+int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream);
+int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float* hits11, int* shape, int* tri, bool stats, hipStream_t stream);
+int launch_ray_trace(const RtwSceneDev* sc, const float* rays, const uint32_t* keys2, long long n, int max_bounce, int preview,
+                     uint32_t seed, unsigned long long npix, float* rgb, void* ws, bool stats, hipStream_t stream);
+int launch_texture_sample(const RtwSceneDev* sc, int shape, int mat, const float* uv, long long n, float* rgba, hipStream_t stream);
+
+}  // namespace rtw

@@ -1,0 +1,694 @@
+// rtw_device.hip -- HIP kernels for gfx950 (CDNA4) and their launch wrappers.
+//
+// Compile with -ffp-contract=off and correctly rounded fp32 divide/sqrt (hipcc default):
+// every float expression below keeps the operand order of the reference so that the GPU
+// result is bit-identical to the CPU oracle.  No MFMA: there is no dense contraction on
+// this path; the hot loop is a stack-free walk over 32-byte nodes (one ray per lane).
+#ifdef RTW_HOST_EMUL      // tests/cpu_emul: the same source compiled for the host, for sanitizer runs only
+#include "rtw_host_emul.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <float.h>
+#include <stdint.h>
+
+#include "rtw_types.h"
+#ifndef RTW_HOST_EMUL
+#include "rtw_device.h"
+#else
+#define RTW_MAX_BOUNCE_DEV 16
+#endif
+
+namespace {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ bool near_zero(float a) { return fabsf(a) < FLT_EPSILON; }   // FLT_EQUAL_ZERO
+__device__ __forceinline__ f3 reflect(f3 v, f3 n) { return v - (n * 2.0f) * dot(v, n); } // Src/RVector.h:218
+__device__ __forceinline__ bool all_nonzero(f3 a) { return !near_zero(a.x) && !near_zero(a.y) && !near_zero(a.z); } // :142
+__device__ __forceinline__ float ref_min(float a, float b) { return (a < b) ? a : b; }  // Math::Min
+__device__ __forceinline__ float ref_max(float a, float b) { return (a > b) ? a : b; }  // Math::Max
+
+__device__ __forceinline__ f3 normalized(f3 v)          // RVec3::GetNormalizedVec3
+{
+    float sq = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (!near_zero(sq)) { float inv = 1.0f / sqrtf(sq); v.x *= inv; v.y *= inv; v.z *= inv; }
+    return v;
+}
+__device__ __forceinline__ float q_rsqrt(float number)  // Math::Q_rsqrt (Src/MathHelper.cpp:26-38)
+{
+    const float x2 = number * 0.5f;
+    float f = __uint_as_float(0x5f3759dfu - (__float_as_uint(number) >> 1));
+    f *= (1.5f - (x2 * f * f));
+    return f;
+}
+__device__ __forceinline__ f3 normalized_fast(f3 v)     // RVec3::GetNormalizedVec3_Fast
+{
+    float sq = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (!near_zero(sq)) { float inv = q_rsqrt(sq); v.x *= inv; v.y *= inv; v.z *= inv; }
+    return v;
+}
+
+// ---- random stream (specification shared with the oracle) --------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__device__ __forceinline__ uint32_t stream_key(uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint32_t h = mix32(seed ^ 0x9E3779B9u);
+    h = mix32(h + pixel);
+    return mix32(h + sample);
+}
+struct PathRng {
+    uint32_t key, counter;
+    uint64_t table_base;    // first unit-table index of the path, phase included, before the modulo
+    uint32_t table_reads;
+    __device__ __forceinline__ float random()            // RMath::Random (Src/Math.h:17-20)
+    {
+        uint32_t r = mix32(key + counter++) >> 1;
+        return (float)(int32_t)r / 2147483648.0f;
+    }
+};
+__device__ __forceinline__ uint32_t table_phase(uint32_t seed) { return mix32(seed ^ 0x7AB1E5u) % RTW_TABLE_SIZE; }   // 32-bit: fine
+__device__ __forceinline__ void rng_init(PathRng& r, uint32_t seed, uint32_t phase, uint64_t npix, uint32_t pixel, uint32_t pass, uint32_t sub)
+{
+    r.key = stream_key(seed, pixel, pass * 4u + sub);
+    r.counter = 0;
+    r.table_base = (((uint64_t)pass * npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
+    r.table_reads = 0;
+}
+
+struct Counters { uint32_t rays, boxes, tris, hits, tex, cams; };
+
+// RTW_BOUNDS_DEBUG build: every indexed global access is range-checked first; a violation is recorded in
+// stats[6] (site code) / stats[7] (offending value) and the access is skipped instead of faulting.
+#ifdef RTW_BOUNDS_DEBUG
+#define RTW_IN_RANGE(sc, code, v, n) rtw_in_range(sc, code, (long long)(v), (long long)(n))
+__device__ __forceinline__ bool rtw_in_range(const RtwSceneDev* sc, int code, long long v, long long n)
+{
+    if (v >= 0 && v < n) return true;
+    if (sc->stats) { atomicMax(&sc->stats[6], (unsigned long long)code); sc->stats[7] = (unsigned long long)v; }
+    return false;
+}
+#else
+#define RTW_IN_RANGE(sc, code, v, n) true
+#endif
+
+struct Ray { f3 o, d; float dist; };
+struct Hit { f3 pos, normal; float dist; f3 color; float alpha; };
+
+// ---- RRay::TestIntersectionWithAabb (Src/RRay.cpp:89-136), exact form ------------------------
+__device__ __forceinline__ bool slab_exact(const Ray& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float& tmin_out, float& tmax_out)
+{
+    float tmin = -FLT_MAX, tmax = FLT_MAX;
+    if (!near_zero(r.d.x)) {
+        float inv = 1.0f / r.d.x;
+        float t1 = (mnx - r.o.x) * inv, t2 = (mxx - r.o.x) * inv;
+        tmin = ref_max(tmin, ref_min(t1, t2)); tmax = ref_min(tmax, ref_max(t1, t2));
+    }
+    if (!near_zero(r.d.y)) {
+        float inv = 1.0f / r.d.y;
+        float t1 = (mny - r.o.y) * inv, t2 = (mxy - r.o.y) * inv;
+        tmin = ref_max(tmin, ref_min(t1, t2)); tmax = ref_min(tmax, ref_max(t1, t2));
+    }
+    if (!near_zero(r.d.z)) {
+        float inv = 1.0f / r.d.z;
+        float t1 = (mnz - r.o.z) * inv, t2 = (mxz - r.o.z) * inv;
+        tmin = ref_max(tmin, ref_min(t1, t2)); tmax = ref_min(tmax, ref_max(t1, t2));
+    }
+    tmin_out = tmin; tmax_out = tmax;
+    return tmax > tmin;
+}
+
+// A ray is "tame" when every direction component is a normal number of magnitude >= FLT_EPSILON
+// and the origin is finite and moderate: then no slab axis is skipped and no NaN/inf can appear,
+// so Math::Min/Max equal v_min/v_max and the reciprocal can be hoisted out of the node loop.
+__device__ __forceinline__ bool ray_is_tame(const Ray& r)
+{
+    const float big = 1.0e15f;
+    return fabsf(r.d.x) >= FLT_EPSILON && fabsf(r.d.y) >= FLT_EPSILON && fabsf(r.d.z) >= FLT_EPSILON &&
+           fabsf(r.d.x) < big && fabsf(r.d.y) < big && fabsf(r.d.z) < big &&
+           fabsf(r.o.x) < big && fabsf(r.o.y) < big && fabsf(r.o.z) < big;
+}
+
+// ---- leaf: RRay::TestIntersectionWithTriangleAndFaceNormal (Src/RRay.cpp:147-213) ------------
+// N and d1 = dot(N, p0) come precomputed from the host (they depend on the triangle only).
+__device__ __forceinline__ bool triangle_test(const Ray& r, float cur_dist, const float4 a, const float4 b, const float4 c, float d1,
+                                              f3& cp_out, float& dist_out)
+{
+    const f3 n = mk(a.w, b.w, c.w);
+    const f3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
+    const f3 end = r.o + r.d * cur_dist;
+    const float d0 = dot(n, r.o);
+    const float d2 = d0 - d1;
+    if (d2 < 0) return false;
+    if (dot(end, n) - d1 > 0) return false;
+    const f3 l = end - r.o;
+    const float d3 = dot(n, l);
+    if (near_zero(d3)) return false;
+    const float df = -(d2 / d3);
+    const f3 cp = r.o + l * df;
+    if (dot(cross(p1 - p0, n), cp - p0) > 0) return false;
+    if (dot(cross(p2 - p1, n), cp - p1) > 0) return false;
+    if (dot(cross(p0 - p2, n), cp - p2) > 0) return false;
+    const f3 ldf = l * df;
+    cp_out = cp;
+    dist_out = sqrtf(ldf.x * ldf.x + ldf.y * ldf.y + ldf.z * ldf.z);
+    return true;
+}
+
+// ---- KdNode::TestRayIntersection (Src/KdTree.cpp:128-195) as a stack-free preorder walk --------
+// Reference order: box miss -> skip subtree; internal hit -> left child (i+1) then right; leaf hit ->
+// triangle test, shrink the segment on accept.  Equal-distance ties keep the LAST accepted leaf.
+// PRUNE adds a segment clip (tmin <= dist+eps, tmax >= -eps): it only skips boxes that cannot hold an
+// accepted hit, so the sequence of accepted hits -- and every output bit -- is unchanged.
+template <bool TAME, bool STATS>
+__device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, const RtwNode* __restrict__ nodes, const RtwTri* __restrict__ tris, int n_nodes, int n_tris,
+                                          const Ray& r, bool prune, float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
+{
+    float ix = 0.f, iy = 0.f, iz = 0.f, eps_t = 0.f;
+    if (TAME) {
+        ix = 1.0f / r.d.x; iy = 1.0f / r.d.y; iz = 1.0f / r.d.z;
+        // positional slack 2e-5 (scene units) expressed along the ray, plus a relative term
+        eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+    }
+    bool any = false;
+    int i = 0;
+    const float4* nd4 = reinterpret_cast<const float4*>(nodes);
+    const float4* tr4 = reinterpret_cast<const float4*>(tris);
+    while (i < n_nodes) {
+        if (!RTW_IN_RANGE(sc, 1, i, n_nodes)) break;
+        const float4 lo = nd4[2 * i], hi = nd4[2 * i + 1];
+        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+        bool hit; float tmin, tmax;
+        if (TAME) {
+            const float x1 = (lo.x - r.o.x) * ix, x2 = (hi.x - r.o.x) * ix;
+            const float y1 = (lo.y - r.o.y) * iy, y2 = (hi.y - r.o.y) * iy;
+            const float z1 = (lo.z - r.o.z) * iz, z2 = (hi.z - r.o.z) * iz;
+            tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+            tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+            hit = tmax > tmin;
+            if (prune) hit = hit && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
+        } else {
+            hit = slab_exact(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, tmin, tmax);
+        }
+        if (STATS) ct.boxes++;
+        if (hit && leaf >= 0 && RTW_IN_RANGE(sc, 2, leaf, n_tris)) {
+            const float4 a = tr4[4 * leaf], b = tr4[4 * leaf + 1], c = tr4[4 * leaf + 2], d = tr4[4 * leaf + 3];
+            if (STATS) ct.tris++;
+            f3 cp; float dist;
+            if (triangle_test(r, cur_dist, a, b, c, d.x, cp, dist)) {
+                cur_dist = dist; hit_pos = cp; hit_slot = leaf; any = true;
+            }
+        }
+        i = (hit && leaf < 0) ? i + 1 : skip;
+    }
+    return any;
+}
+
+// ---- RTexture::Sample (Src/Texture.cpp:23-57) on RGBA8 texels + the host LUT ---------------------
+__device__ __forceinline__ void texel_fetch(const uint32_t* __restrict__ tex, const float* __restrict__ lut, int idx, float& r, float& g, float& b, float& a)
+{
+    const uint32_t t = tex[idx];
+    r = lut[t & 255u]; g = lut[(t >> 8) & 255u]; b = lut[(t >> 16) & 255u];
+    a = (float)(t >> 24) / 255;
+}
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ void texture_sample(const uint32_t* __restrict__ texels, const RtwTexture& t, const float* __restrict__ lut,
+                                               float u, float v, f3& rgb, float& alpha)
+{
+    const float cu = u - floorf(u), cv = v - floorf(v);
+    const float fx = cu * (t.width - 1), fy = cv * (t.height - 1);
+    int x0 = (int)floorf(fx), y0 = (int)floorf(fy), x1 = (int)ceilf(fx), y1 = (int)ceilf(fy);
+    const float dx = fx - x0, dy = fy - y0;
+    // finite uv always land inside the image; NaN/inf uv (undefined behaviour in the reference) must not fault
+    x0 = min(max(x0, 0), t.width - 1); x1 = min(max(x1, 0), t.width - 1);
+    y0 = min(max(y0, 0), t.height - 1); y1 = min(max(y1, 0), t.height - 1);
+    const uint32_t* base = texels + t.offset;
+    float r00, g00, b00, a00, r01, g01, b01, a01, r10, g10, b10, a10, r11, g11, b11, a11;
+    texel_fetch(base, lut, y0 * t.width + x0, r00, g00, b00, a00);
+    texel_fetch(base, lut, y0 * t.width + x1, r01, g01, b01, a01);
+    texel_fetch(base, lut, y1 * t.width + x0, r10, g10, b10, a10);
+    texel_fetch(base, lut, y1 * t.width + x1, r11, g11, b11, a11);
+    rgb.x = lerpf(lerpf(r00, r01, dx), lerpf(r10, r11, dx), dy);
+    rgb.y = lerpf(lerpf(g00, g01, dx), lerpf(g10, g11, dx), dy);
+    rgb.z = lerpf(lerpf(b00, b01, dx), lerpf(b10, b11, dx), dy);
+    alpha = lerpf(lerpf(a00, a01, dx), lerpf(a10, a11, dx), dy);
+}
+
+// ---- RMeshShape::TestRayIntersection (Src/MeshShape.cpp:280-332) ------------------------------------
+template <bool STATS>
+__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, const Ray& r, float seg_dist,
+                                           Hit& out, int& tri_index, Counters& ct)
+{
+    float cur = seg_dist; f3 pos = mk(0, 0, 0); int slot = -1;
+    bool any;
+    if (ray_is_tame(r)) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, ct);
+    else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, ct);
+    if (!any) return false;
+    if (!RTW_IN_RANGE(sc, 3, slot, sh.n_tris)) return false;
+    if (STATS) ct.hits++;
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    const float4 ta = tr4[4 * slot], tb = tr4[4 * slot + 1], tc = tr4[4 * slot + 2], td = tr4[4 * slot + 3];
+    tri_index = __float_as_int(td.y);
+    const f3 a = mk(ta.x, ta.y, ta.z), b = mk(tb.x, tb.y, tb.z), c = mk(tc.x, tc.y, tc.z);
+    // RMath::Barycentric (Src/Math.cpp:56-68)
+    const f3 v0 = b - a, v1 = c - a, v2 = pos - a;
+    const float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    const float bv = (d11 * d20 - d01 * d21) / denom;
+    const float bw = (d00 * d21 - d01 * d20) / denom;
+    const float bu = 1.0f - bv - bw;
+    const float4* sh4 = reinterpret_cast<const float4*>(sh.shade);
+    const float4 s0 = sh4[4 * slot], s1 = sh4[4 * slot + 1], s2 = sh4[4 * slot + 2], s3 = sh4[4 * slot + 3];
+    const f3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
+    out.pos = pos;
+    out.dist = cur;
+    out.normal = normalized_fast((n0 * bu + n1 * bv) + n2 * bw);
+    out.color = mk(1.0f, 1.0f, 1.0f);      // *OutResult = HitResult resets the sampled colour (Src/KdTree.cpp:176)
+    out.alpha = 1.0f;
+    const int mat = __float_as_int(s3.w);
+    if (mat != -1 && mat < sh.n_textures && mat < RTW_DEV_MAX_TEXTURES && sh.textures[mat].valid) {
+        const float tu = (s2.y * bu + s2.w * bv) + s3.y * bw;      // t0*u + t1*v + t2*w
+        const float tv = (s2.z * bu + s3.x * bv) + s3.z * bw;
+        if (STATS) ct.tex++;
+        texture_sample(sh.texels, sh.textures[mat], sc->texel_lut, tu, 1.0f - tv, out.color, out.alpha);
+    }
+    return true;
+}
+
+// ---- RayTracerScene::FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) ------------------------
+template <bool STATS>
+__device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__ sc, const Ray& in, Hit& out, int& tri_index, Counters& ct)
+{
+    int hit_shape = -1;
+    float seg = in.dist;
+    if (STATS) ct.rays++;
+    for (int s = 0; s < sc->n_shapes; s++) {
+        const RtwShapeDev& sh = sc->shapes[s];
+        float t0, t1;
+        if (STATS) ct.boxes++;
+        if (!slab_exact(in, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+        if (mesh_query<STATS>(sc, sh, in, seg, out, tri_index, ct)) { seg = out.dist; hit_shape = s; }
+    }
+    return hit_shape;
+}
+
+// ---- materials (Src/SurfaceMaterials.cpp:20-187), flattened tree, explicit evaluation stack -------------
+struct Bounce { f3 att, em; };
+
+__device__ __forceinline__ f3 unit_vector_f64(float r1, float r2)     // RMath::RandomUnitVector, double transcendentals
+{
+    const float t1 = 2.0f * 3.1415926f * r1;
+    const float t2 = (float)acos((double)(1.0f - 2.0f * r2));
+    const float sin_t2 = (float)sin((double)t2);
+    return mk((float)sin((double)t1) * sin_t2, (float)cos((double)t1) * sin_t2, (float)cos((double)t2));
+}
+// x mod (2^24 - 1) by digit folding (2^24 == 1 mod 2^24-1).  Written out because hipcc (ROCm 7.2) lowered
+// `uint64 % 0xFFFFFF` on gfx950 to a sequence that left values outside the table (GPU memory fault at
+// 1920x1080, where the per-path cursor first exceeds the table size); exact for every 64-bit x.
+__device__ __forceinline__ uint32_t mod_table_size(uint64_t x)
+{
+    uint32_t s = (uint32_t)(x & 0xFFFFFFu) + (uint32_t)((x >> 24) & 0xFFFFFFu) + (uint32_t)(x >> 48);   // < 2^26
+    s = (s & 0xFFFFFFu) + (s >> 24);                                                                     // < 2^24 + 4
+    if (s >= RTW_TABLE_SIZE) s -= RTW_TABLE_SIZE;
+    if (s >= RTW_TABLE_SIZE) s -= RTW_TABLE_SIZE;
+    return s;
+}
+__device__ __forceinline__ f3 hemisphere_direction(const RtwSceneDev* __restrict__ sc, f3 normal, PathRng& rng)
+{
+    const uint32_t idx = mod_table_size(rng.table_base + rng.table_reads);   // RMath::PseudoRandomUnitVector, per-path cursor
+    rng.table_reads++;
+    if (!RTW_IN_RANGE(sc, 4, idx, RTW_TABLE_SIZE)) return normal;
+    const float* e = sc->unit_table + (size_t)idx * 3;
+    const f3 v = mk(e[0], e[1], e[2]);
+    if (dot(v, normal) > 0.0f) return v;                                          // Src/Math.cpp:42-54
+    return reflect(v, normal);
+}
+__device__ __forceinline__ bool checker_brighter(f3 p, float size)
+{
+    const float recip = near_zero(size) ? 1.0f : 1.0f / size;
+    bool r = false;
+    const float fx = p.x * recip, fy = p.y * recip, fz = p.z * recip;
+    if (fx - floorf(fx) > 0.5f) r = !r;
+    if (fz - floorf(fz) > 0.5f) r = !r;
+    if (fy - floorf(fy) > 0.5f) r = !r;
+    return r;
+}
+
+__device__ __forceinline__ Bounce leaf_bounce(const RtwSceneDev* __restrict__ sc, const RtwMaterialNode& n, const Ray& in, const Hit& h, Ray& out, PathRng& rng)
+{
+    Bounce b; b.att = mk(0, 0, 0); b.em = mk(0, 0, 0);
+    const f3 albedo = mk(n.r, n.g, n.b);
+    switch (n.type) {
+    case 0: case 1: {
+        const float factor = (n.type == 1) ? (checker_brighter(h.pos, n.param) ? 1.0f : 0.5f) : 1.0f;
+        const float rd = in.dist - h.dist;
+        const f3 dir = hemisphere_direction(sc, h.normal, rng);
+        out.o = h.pos + dir * 0.0001f; out.d = dir; out.dist = rd;
+        const float d = ref_max(0.0f, dot(h.normal, dir));
+        b.att = albedo * d;
+        if (n.type == 1) b.att = b.att * factor;
+        break;
+    }
+    case 2: {
+        const float rd = in.dist - h.dist;
+        f3 nd = reflect(in.d, h.normal);
+        if (n.param > 0.0f) {
+            const float r1 = rng.random();
+            const float r2 = rng.random();
+            nd = nd + unit_vector_f64(r1, r2) * n.param;
+            nd = normalized(nd);
+        }
+        out.o = h.pos + nd * 0.0001f; out.d = nd; out.dist = rd;
+        b.att = albedo;
+        break;
+    }
+    case 3: out = in; b.em = albedo; break;
+    default: {
+        const float rd = in.dist - h.dist;
+        out.o = h.pos + in.d * 0.0001f; out.d = in.d; out.dist = rd;
+        b.att = mk(1, 1, 1);
+        break;
+    }
+    }
+    return b;
+}
+__device__ __forceinline__ f3 leaf_preview(const RtwMaterialNode& n, const Hit& h)
+{
+    const f3 albedo = mk(n.r, n.g, n.b);
+    switch (n.type) {
+    case 0: return albedo * (dot(h.normal, mk(0, 1, 0)) * 0.5f + 0.5f);
+    case 1: return (albedo * (dot(h.normal, mk(0, 1, 0)) * 0.5f + 0.5f)) * (checker_brighter(h.pos, n.param) ? 1.0f : 0.5f);
+    case 2: case 3: return albedo;
+    default: return mk(0, 0, 0);
+    }
+}
+
+// Evaluate BounceViewRay (PREVIEW=false) or PreviewColor (PREVIEW=true) of a material tree.
+// Combine evaluates its B operand first (what g++ 11 does for A(...) + B(...); pinned by oracle/_ref),
+// then adds A + B.  `att` carries the preview colour when PREVIEW.
+#define RTW_EVAL_DEPTH 2
+// Combine nesting is limited to RTW_EVAL_DEPTH = 2 so that the evaluation stack is two named register
+// sets (no dynamically indexed private array, hence no scratch memory).
+template <bool PREVIEW>
+__device__ __forceinline__ Bounce material_eval(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, const Ray& in, const Hit& h, Ray& out, PathRng& rng)
+{
+    int node0 = 0, node1 = 0, phase0 = 0, phase1 = 0;
+    Bounce saved0, saved1;
+    saved0.att = saved0.em = saved1.att = saved1.em = mk(0, 0, 0);
+    int sp = 0;
+    int cur = 0;
+    Bounce res; res.att = mk(0, 0, 0); res.em = mk(0, 0, 0);
+    for (;;) {
+        const RtwMaterialNode n = sh.material[cur];
+        if (n.type == 4) {                       // Blend: Random() > factor ? A : B  (factor clamped to [0,1])
+            const float bf = n.param < 0.0f ? 0.0f : (n.param > 1.0f ? 1.0f : n.param);
+            cur = rng.random() > bf ? n.child_a : n.child_b;
+            continue;
+        }
+        if (n.type == 5 && sp < RTW_EVAL_DEPTH) {
+            if (sp == 0) { node0 = cur; phase0 = 0; } else { node1 = cur; phase1 = 0; }
+            sp++;
+            cur = n.child_b;
+            continue;
+        }
+        if (PREVIEW) { res.att = leaf_preview(n, h); res.em = mk(0, 0, 0); }
+        else res = leaf_bounce(sc, n, in, h, out, rng);
+        bool have_result = true;
+        while (have_result) {
+            if (sp == 0) return res;
+            const bool top0 = (sp == 1);
+            const int phase = top0 ? phase0 : phase1;
+            if (phase == 0) {                    // B done: keep it, evaluate A
+                if (top0) { saved0 = res; phase0 = 1; cur = sh.material[node0].child_a; }
+                else { saved1 = res; phase1 = 1; cur = sh.material[node1].child_a; }
+                have_result = false;
+            } else {                             // A done: A + B
+                const Bounce sb = top0 ? saved0 : saved1;
+                res.att = res.att + sb.att;
+                res.em = res.em + sb.em;
+                sp--;
+            }
+        }
+    }
+}
+
+// ---- RayTracerScene::RayTrace (Src/RayTracerScene.cpp:31-97): recursion -> walk forward, fold back ----------
+// The per-level factors of the recursion live in a global workspace, structure-of-arrays over the
+// launch's threads (slot (level, j) of thread t = ws[(level * 3 + j) * stride + t]): coalesced, no
+// scratch.  j = 0: attenuation + kind (0 opaque with child, 2 transparent pass-through),
+// j = 1: sampled colour, j = 2: emissive.
+struct LevelStore {
+    float4* __restrict__ ws; size_t stride; size_t tid;
+    __device__ __forceinline__ float4& at(int level, int j) const { return ws[((size_t)level * 3 + (size_t)j) * stride + tid]; }
+};
+
+template <bool STATS>
+__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv)
+{
+    int nlev = 0;
+    f3 L = mk(0, 0, 0);
+    int depth = max_bounce;
+    for (;;) {
+        if (depth == 0) { L = mk(0, 0, 0); break; }
+        Hit h; int tri;
+        const int s = find_intersection<STATS>(sc, ray, h, tri, ct);
+        if (s < 0) {                                                     // sky (Src/RayTracerScene.cpp:89-94)
+            const float t = 0.5f * (ray.d.y + 1.0f);
+            L = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
+            break;
+        }
+        const RtwShapeDev& sh = sc->shapes[s];
+        if (!sh.has_material) { L = mk(0, 0, 0); break; }
+        Ray out = ray;
+        if (preview) {
+            const Bounce p = material_eval<true>(sc, sh, ray, h, out, rng);
+            L = mk(0, 0, 0) + p.att * h.color;
+            break;
+        }
+        const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
+        if (!RTW_IN_RANGE(sc, 5, nlev, max_bounce)) { L = mk(0, 0, 0); break; }
+        if (rng.random() <= h.alpha) {
+            if (all_nonzero(b.att)) {
+                lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
+                lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+                nlev++;
+                ray = out; depth--;
+                continue;
+            }
+            L = mk(0, 0, 0) + b.em;
+            break;
+        }
+        // transparent texel: same direction, remaining distance, no colour factor
+        lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+        nlev++;
+        const float rd = ray.dist - h.dist;
+        ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
+        depth--;
+    }
+    for (int k = nlev - 1; k >= 0; k--) {
+        const float4 a = lv.at(k, 0);
+        if (__float_as_int(a.w) == 0) {
+            const float4 c = lv.at(k, 1), e = lv.at(k, 2);
+            L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
+        } else {
+            L = mk(0, 0, 0) + L;
+        }
+    }
+    return L;
+}
+
+// ---- camera + resolve (Src/RayTracerProgram.cpp:131-188, Src/ColorBuffer.h:81-109) ---------------------------
+__device__ __forceinline__ Ray camera_ray(int width, int height, int pixel, int i, PathRng& rng)
+{
+    const float aspect = (float)width / (float)height;
+    const int x = pixel % width, y = pixel / width;
+    const float dx = -(float)(x - width / 2) / (width * 2) * aspect;
+    const float dy = -(float)(y - height / 2) / (height * 2);
+    const float inv_pixel_radius = 1.0f / (width * 4);
+    const float offset_radius = inv_pixel_radius * 0.5f;
+    float ox = (i & 1) ? inv_pixel_radius : 0.0f;
+    float oy = (i & 2) ? inv_pixel_radius : 0.0f;
+    ox += (rng.random() - 0.5f) * offset_radius;
+    oy += (rng.random() - 0.5f) * offset_radius;
+    Ray r;
+    r.o = mk(0, 0, 7.0f);
+    r.d = normalized(mk(dx + ox, dy + oy, -0.5f));
+    r.dist = 1000.0f;
+    return r;
+}
+
+// 8-bit value of MakePixelColor(LinearToGamma(c)) for one channel: the largest k with thr[k] <= c.
+// A fast exp2/log2 guess is corrected against the exact host thresholds, so the guess quality
+// affects speed only.
+__device__ __forceinline__ uint32_t gamma_channel(const float* __restrict__ thr, float c)
+{
+    if (!(c > 0.0f)) return 0u;
+    if (c >= 1.0f) return 255u;
+    int k = (int)(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 2.2f)) * 255.0f);
+    k = k < 0 ? 0 : (k > 255 ? 255 : k);
+    while (k < 255 && thr[k + 1] <= c) k++;
+    while (k > 0 && thr[k] > c) k--;
+    return (uint32_t)k;
+}
+__device__ __forceinline__ uint32_t pack_pixel(const float* __restrict__ thr, f3 c)
+{
+    return (255u << 24) | (gamma_channel(thr, c.x) << 16) | (gamma_channel(thr, c.y) << 8) | gamma_channel(thr, c.z);
+}
+
+__device__ __forceinline__ void flush_counters(const RtwSceneDev* __restrict__ sc, const Counters& ct)
+{
+    if (!sc->stats) return;
+    atomicAdd(&sc->stats[0], (unsigned long long)ct.rays);
+    atomicAdd(&sc->stats[1], (unsigned long long)ct.boxes);
+    atomicAdd(&sc->stats[2], (unsigned long long)ct.tris);
+    atomicAdd(&sc->stats[3], (unsigned long long)ct.hits);
+    atomicAdd(&sc->stats[4], (unsigned long long)ct.tex);
+    atomicAdd(&sc->stats[5], (unsigned long long)ct.cams);
+}
+
+__device__ __forceinline__ int work_to_pixel(const RtwRenderParams& p, int wi)
+{
+    if (p.world <= 1) return p.begin + wi;
+    const int per_task = p.task_rows * p.width;
+    const int j = wi / per_task, r = wi - j * per_task;
+    return (j * p.world + p.rank) * per_task + r;
+}
+
+// ---- kernels -----------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
+                                                     uint32_t* __restrict__ argb, float4* __restrict__ ws, RtwRenderParams p)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
+    __syncthreads();
+    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= p.count) return;
+    const int pixel = work_to_pixel(p, wi);
+    const int npix = p.width * p.height;
+    if (pixel >= npix) return;
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    const uint32_t phase = table_phase(p.seed);
+    LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi;
+    if (!RTW_IN_RANGE(sc, 6, pixel, npix)) return;
+    f3 c = mk(0, 0, 0);
+    for (int i = 0; i < p.sub_samples; i++) {
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
+        const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
+        if (STATS) ct.cams++;
+        c = c + trace_path<STATS>(sc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+    }
+    c = c / (float)p.sub_samples;
+    if (p.preview) {
+        argb[pixel] = pack_pixel(thr, c);
+    } else {
+        float4 a = accum[pixel];
+        const f3 sum = mk(a.x, a.y, a.z) + c;
+        const int n = __float_as_int(a.w) + 1;
+        accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+        argb[pixel] = pack_pixel(thr, sum / (float)n);
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void closest_kernel(const RtwSceneDev* __restrict__ sc, const float* __restrict__ rays, long long n,
+                                                      float* __restrict__ hits11, int* __restrict__ shape, int* __restrict__ tri)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = mk(rays[i * 7], rays[i * 7 + 1], rays[i * 7 + 2]); r.d = mk(rays[i * 7 + 3], rays[i * 7 + 4], rays[i * 7 + 5]); r.dist = rays[i * 7 + 6];
+    Hit h; h.pos = mk(0, 0, 0); h.normal = mk(0, 0, 0); h.dist = 0.0f; h.color = mk(1, 1, 1); h.alpha = 1.0f;   // RayHitResult()
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    int t = -1;
+    const int s = find_intersection<STATS>(sc, r, h, t, ct);
+    float* o = hits11 + i * 11;
+    o[0] = h.pos.x; o[1] = h.pos.y; o[2] = h.pos.z; o[3] = h.normal.x; o[4] = h.normal.y; o[5] = h.normal.z; o[6] = h.dist;
+    o[7] = h.color.x; o[8] = h.color.y; o[9] = h.color.z; o[10] = h.alpha;
+    shape[i] = s; tri[i] = s >= 0 ? t : -1;
+    if (STATS) flush_counters(sc, ct);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void ray_trace_kernel(const RtwSceneDev* __restrict__ sc, const float* __restrict__ rays,
+                                                        const uint32_t* __restrict__ keys2, long long n, int max_bounce, int preview,
+                                                        uint32_t seed, unsigned long long npix, float* __restrict__ rgb, float4* __restrict__ ws)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = mk(rays[i * 7], rays[i * 7 + 1], rays[i * 7 + 2]); r.d = mk(rays[i * 7 + 3], rays[i * 7 + 4], rays[i * 7 + 5]); r.dist = rays[i * 7 + 6];
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    const uint32_t pixel = keys2[i * 2], sample = keys2[i * 2 + 1];
+    PathRng rng; rng_init(rng, seed, table_phase(seed), npix, pixel, sample / 4u, sample % 4u);
+    LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)i;
+    const f3 c = trace_path<STATS>(sc, r, max_bounce, preview != 0, rng, ct, lv);
+    rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
+    if (STATS) flush_counters(sc, ct);
+}
+
+__global__ void texture_sample_kernel(const RtwSceneDev* __restrict__ sc, int shape, int mat, const float* __restrict__ uv, long long n, float* __restrict__ rgba)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RtwShapeDev& sh = sc->shapes[shape];
+    f3 c; float a;
+    texture_sample(sh.texels, sh.textures[mat], sc->texel_lut, uv[i * 2], uv[i * 2 + 1], c, a);
+    rgba[i * 4] = c.x; rgba[i * 4 + 1] = c.y; rgba[i * 4 + 2] = c.z; rgba[i * 4 + 3] = a;
+}
+
+}  // namespace
+
+#ifndef RTW_HOST_EMUL
+// ---- launch wrappers ---------------------------------------------------------------------------------------
+namespace rtw {
+
+int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream)
+{
+    if (p.count <= 0) return 0;
+    const int block = 256;
+    const int grid = (p.count + block - 1) / block;
+    if (stats) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, (float4*)ws, p);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, (float4*)ws, p);
+    return (int)hipGetLastError();
+}
+
+int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float* hits11, int* shape, int* tri, bool stats, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    const int block = 256;
+    const unsigned grid = (unsigned)((n + block - 1) / block);
+    if (stats) hipLaunchKernelGGL(closest_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, rays, n, hits11, shape, tri);
+    else hipLaunchKernelGGL(closest_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, rays, n, hits11, shape, tri);
+    return (int)hipGetLastError();
+}
+
+int launch_ray_trace(const RtwSceneDev* sc, const float* rays, const uint32_t* keys2, long long n, int max_bounce, int preview,
+                     uint32_t seed, unsigned long long npix, float* rgb, void* ws, bool stats, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    const int block = 256;
+    const unsigned grid = (unsigned)((n + block - 1) / block);
+    if (stats) hipLaunchKernelGGL(ray_trace_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, rays, keys2, n, max_bounce, preview, seed, npix, rgb, (float4*)ws);
+    else hipLaunchKernelGGL(ray_trace_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, rays, keys2, n, max_bounce, preview, seed, npix, rgb, (float4*)ws);
+    return (int)hipGetLastError();
+}
+
+int launch_texture_sample(const RtwSceneDev* sc, int shape, int mat, const float* uv, long long n, float* rgba, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    const int block = 256;
+    const unsigned grid = (unsigned)((n + block - 1) / block);
+    hipLaunchKernelGGL(texture_sample_kernel, dim3(grid), dim3(block), 0, stream, sc, shape, mat, uv, n, rgba);
+    return (int)hipGetLastError();
+}
+
+}  // namespace rtw
+#endif  // RTW_HOST_EMUL

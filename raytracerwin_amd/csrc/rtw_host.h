@@ -1,0 +1,57 @@
+// rtw_host.h -- host-side scene library (internal).  C++17, no HIP types.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rtw_types.h"
+
+namespace rtw {
+
+struct Vec3 { float x, y, z; };
+
+struct HostTexture {
+    int width = 0, height = 0;
+    std::vector<uint32_t> rgba8;      // R | G<<8 | B<<16 | A<<24
+    bool valid = false;
+};
+
+// The arrays RMeshShape owns (Src/MeshShape.h:25-37) plus the flattened tree.
+struct HostMesh {
+    std::vector<Vec3> points, texcoords, normals;
+    std::vector<int32_t> point_idx, texcoord_idx, normal_idx;   // 3 per triangle
+    std::vector<int32_t> poly_material;                         // per triangle
+    std::vector<std::string> material_names;
+    std::vector<std::string> texture_paths;                     // per material id ("" = none)
+    std::vector<HostTexture> textures;                          // per material id
+    int n_textures_slots = 0;          // size of the reference's Textures vector (0 without an MTL)
+    float bmin[3], bmax[3];            // RShape::Aabb
+    std::vector<RtwMaterialNode> material;
+    // built by build_tree():
+    std::vector<RtwNode> nodes;
+    std::vector<RtwTri> tris;          // leaf order
+    std::vector<RtwShade> shade;       // leaf order
+    int max_depth = 0;
+    int n_tris() const { return (int)(point_idx.size() / 3); }
+};
+
+// OBJ + MTL (+ PNG) with the reference parser's semantics (Src/MeshShape.cpp:65-278).
+// Returns empty string on success, else an error message.
+std::string load_obj(const std::string& path, HostMesh& out);
+// Validate index ranges; compute bounds if `bounds6` is null.
+std::string finish_arrays(HostMesh& m, const float* bounds6);
+// KdNode::Build restated (Src/KdTree.cpp:37-126) + flatten to preorder/skip-link form.
+void build_tree(HostMesh& m);
+
+// tables
+uint32_t rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);
+void unit_table_entry(uint32_t index, float out3[3]);
+void fill_unit_table(float* dst /* 3 * RTW_TABLE_SIZE floats */, int threads);
+void gamma_thresholds(float out256[256]);
+void texel_lut(float out256[256]);
+
+// PNG (8-bit RGB / RGBA, non-interlaced or Adam7) on zlib
+std::string png_load(const std::string& path, std::vector<uint8_t>& texels, int& w, int& h, int& channels);
+std::string png_save_rgb(const std::string& path, const uint8_t* rgb, int w, int h);
+
+}  // namespace rtw

@@ -1,0 +1,84 @@
+// rtw_types.h -- plain-data layouts shared by the host scene builder and the HIP kernels.
+//
+// HBM layout (per committed scene; everything read-only while rendering):
+//   nodes   RtwNode[2T-1]   32 B   preorder, left child = i+1, `skip` = next node after the subtree
+//   tris    RtwTri[T]       64 B   leaf order: 3 positions + face normal + plane offset + original index
+//   shade   RtwShade[T]     64 B   leaf order: 3 vertex normals, 3 uv pairs, material id
+//   texels  uint32[...]     RGBA8 atlas, one slab per texture; linearised through a 256-entry LUT
+//   unit    float[3*0xFFFFFF]  the reference's pseudo-random unit-vector table (per context)
+#pragma once
+#include <stdint.h>
+
+struct RtwNode {            // 2 x 16 B
+    float min_x, min_y, min_z; int32_t skip;
+    float max_x, max_y, max_z; int32_t tri;      // leaf slot, or -1 for an internal node
+};
+static_assert(sizeof(RtwNode) == 32, "RtwNode");
+
+struct RtwTri {             // 4 x 16 B
+    float p0x, p0y, p0z, nx;
+    float p1x, p1y, p1z, ny;
+    float p2x, p2y, p2z, nz;
+    float d1; int32_t orig; int32_t pad0, pad1;  // d1 = dot(N, p0); orig = triangle index in the mesh
+};
+static_assert(sizeof(RtwTri) == 64, "RtwTri");
+
+struct RtwShade {           // 4 x 16 B
+    float n0x, n0y, n0z, n1x;
+    float n1y, n1z, n2x, n2y;
+    float n2z, u0, v0, u1;
+    float v1, u2, v2; int32_t material;
+};
+static_assert(sizeof(RtwShade) == 64, "RtwShade");
+
+struct RtwTexture {         // 16 B
+    uint32_t offset;        // first texel in the atlas
+    int32_t width, height;
+    int32_t valid;
+};
+
+struct RtwMaterialNode {    // mirrors rtw_material_node
+    int32_t type; float r, g, b; float param; int32_t child_a, child_b; int32_t pad;
+};
+
+#define RTW_DEV_MAX_TEXTURES 64
+#define RTW_DEV_MAX_MATERIAL_NODES 64
+#define RTW_DEV_MAX_SHAPES 8
+
+struct RtwShapeDev {
+    const RtwNode* nodes;
+    const RtwTri* tris;
+    const RtwShade* shade;
+    const uint32_t* texels;
+    float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
+    int32_t n_nodes, n_tris;
+    int32_t n_textures;             // size of the reference's Textures vector (= triangle count when an MTL exists)
+    int32_t has_material;
+    int32_t n_material_nodes;
+    int32_t pad;
+    RtwTexture textures[RTW_DEV_MAX_TEXTURES];
+    RtwMaterialNode material[RTW_DEV_MAX_MATERIAL_NODES];
+};
+
+struct RtwSceneDev {
+    int32_t n_shapes;
+    int32_t prune;
+    const float* unit_table;        // 3 floats per entry
+    const float* gamma_thr;         // 256
+    const float* texel_lut;         // 256
+    unsigned long long* stats;      // 8 counters or nullptr
+    RtwShapeDev shapes[RTW_DEV_MAX_SHAPES];
+};
+
+struct RtwRenderParams {
+    int32_t width, height;
+    int32_t begin, count;           // linear work items: pixel = map(begin + i)
+    int32_t task_rows, rank, world; // world <= 1: contiguous range
+    int32_t max_bounce, preview, pass_index, sub_samples;
+    uint32_t seed;
+};
+
+// random-stream constants (shared with the oracle by specification, not by code)
+#define RTW_TABLE_SIZE 0xFFFFFFu
+#define RTW_TABLE_STRIDE 16u
+#define RTW_TABLE_SEED 0x52544142u

@@ -1,0 +1,651 @@
+// rtwin_capi.cpp -- the C ABI declared in include/rtwin.h, over the HIP runtime.
+// There is deliberately no CPU fallback: every device entry point needs a HIP device.
+#include "../../include/rtwin.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <climits>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rtw_device.h"
+#include "rtw_host.h"
+
+static_assert(sizeof(rtw_material_node) == sizeof(RtwMaterialNode), "material node layout");
+static_assert(RTW_MAX_BOUNCE == RTW_MAX_BOUNCE_DEV, "bounce limit");
+static_assert(RTW_UNIT_TABLE_SIZE == RTW_TABLE_SIZE, "table size");
+
+namespace {
+
+thread_local std::string t_error;
+int fail(int code, const std::string& msg) { t_error = msg; return code; }
+int hip_fail(hipError_t e, const char* what)
+{
+    return fail(RTW_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
+
+// host copy of the unit-vector table, generated once per process
+std::mutex g_table_mutex;
+std::vector<float> g_unit_table;
+const std::vector<float>& host_unit_table()
+{
+    std::lock_guard<std::mutex> l(g_table_mutex);
+    if (g_unit_table.empty()) {
+        g_unit_table.resize((size_t)RTW_TABLE_SIZE * 3);
+        int th = (int)std::thread::hardware_concurrency();
+        rtw::fill_unit_table(g_unit_table.data(), th > 0 ? th : 1);
+    }
+    return g_unit_table;
+}
+
+}  // namespace
+
+struct rtw_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* d_unit = nullptr;
+    float* d_gamma = nullptr;
+    float* d_lut = nullptr;
+    unsigned long long* d_stats = nullptr;
+    bool stats_enabled = false;
+    void* d_workspace = nullptr;        // per-launch level store of the bounce recursion (grown on demand)
+    size_t workspace_bytes = 0;
+};
+
+struct rtw_scene {
+    rtw_context* ctx = nullptr;
+    std::vector<std::unique_ptr<rtw::HostMesh>> meshes;
+    bool committed = false;
+    int prune = 1;
+    RtwSceneDev* d_scene = nullptr;
+    std::vector<void*> allocs;
+};
+
+struct rtw_framebuffer {
+    rtw_context* ctx = nullptr;
+    int width = 0, height = 0;
+    void* accum = nullptr;
+    void* argb = nullptr;
+    bool owned = false;
+};
+
+namespace {
+template <typename T>
+int upload(rtw_scene* scene, const std::vector<T>& v, const T** out)
+{
+    *out = nullptr;
+    if (v.empty()) return RTW_OK;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(T)));
+    scene->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return RTW_OK;
+}
+
+// make sure the context's level workspace holds `bytes`; growing waits for the stream first
+int ensure_workspace(rtw_context* ctx, size_t bytes)
+{
+    if (bytes <= ctx->workspace_bytes) return RTW_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_workspace) { (void)hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_bytes = 0; }
+    HIP_TRY(hipMalloc(&ctx->d_workspace, bytes));
+    ctx->workspace_bytes = bytes;
+    return RTW_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rtw_last_error(void) { return t_error.c_str(); }
+const char* rtw_version(void) { return "rtwin 0.1 (gfx950)"; }
+
+int rtw_context_create(int device_index, rtw_context** out)
+{
+    if (!out) return fail(RTW_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(RTW_ERR_NO_DEVICE, "no HIP device: librtwin has no CPU fallback");
+    if (device_index < 0 || device_index >= count) return fail(RTW_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device_index));
+    std::unique_ptr<rtw_context> c(new rtw_context());
+    c->device = device_index;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    const std::vector<float>& tab = host_unit_table();
+    HIP_TRY(hipMalloc((void**)&c->d_unit, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->d_unit, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    float thr[256], lut[256];
+    rtw::gamma_thresholds(thr);
+    rtw::texel_lut(lut);
+    HIP_TRY(hipMalloc((void**)&c->d_gamma, sizeof thr));
+    HIP_TRY(hipMalloc((void**)&c->d_lut, sizeof lut));
+    HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)));
+    *out = c.release();
+    return RTW_OK;
+}
+
+int rtw_context_destroy(rtw_context* ctx)
+{
+    if (!ctx) return RTW_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_unit); (void)hipFree(ctx->d_workspace); (void)hipFree(ctx->d_gamma); (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_stats);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RTW_OK;
+}
+
+int rtw_context_set_stream(rtw_context* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    ctx->stream = (hipStream_t)hip_stream;
+    return RTW_OK;
+}
+
+int rtw_context_synchronize(rtw_context* ctx)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RTW_OK;
+}
+
+// ---- scene ------------------------------------------------------------------------------------------
+int rtw_scene_create(rtw_context* ctx, rtw_scene** out)
+{
+    // ctx may be NULL: a host-only scene (parse + build + inspect), every device query then fails
+    if (!out) return fail(RTW_ERR_INVALID, "null argument");
+    *out = new rtw_scene();
+    (*out)->ctx = ctx;
+    return RTW_OK;
+}
+
+int rtw_scene_destroy(rtw_scene* scene)
+{
+    if (!scene) return RTW_OK;
+    if (scene->ctx) {
+        (void)hipSetDevice(scene->ctx->device);
+        (void)hipStreamSynchronize(scene->ctx->stream);
+    }
+    for (void* p : scene->allocs) (void)hipFree(p);
+    delete scene;
+    return RTW_OK;
+}
+
+static int default_material(rtw::HostMesh& m)
+{
+    m.material.clear();     // a shape added without a material has none (RayTrace then returns black)
+    return 0;
+}
+
+int rtw_scene_add_mesh_obj(rtw_scene* scene, const char* obj_path, int* out_shape)
+{
+    if (!scene || !obj_path) return fail(RTW_ERR_INVALID, "null argument");
+    if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
+    if ((int)scene->meshes.size() >= RTW_DEV_MAX_SHAPES) return fail(RTW_ERR_LIMIT, "too many shapes");
+    std::unique_ptr<rtw::HostMesh> m(new rtw::HostMesh());
+    const std::string err = rtw::load_obj(obj_path, *m);
+    if (!err.empty()) return fail(RTW_ERR_IO, err);
+    if ((int)m->material_names.size() > RTW_MAX_MESH_MATERIALS) return fail(RTW_ERR_LIMIT, "too many materials in mesh");
+    default_material(*m);
+    scene->meshes.push_back(std::move(m));
+    if (out_shape) *out_shape = (int)scene->meshes.size() - 1;
+    return RTW_OK;
+}
+
+int rtw_scene_add_mesh(rtw_scene* scene, const float* positions, int n_positions, const float* texcoords, int n_texcoords,
+                       const float* normals, int n_normals, const int32_t* idx_p, const int32_t* idx_t, const int32_t* idx_n,
+                       const int32_t* tri_material, int n_tris, const float* shape_bounds6, int* out_shape)
+{
+    if (!scene || !positions || !texcoords || !normals || !idx_p || !idx_t || !idx_n || n_tris < 0)
+        return fail(RTW_ERR_INVALID, "null argument");
+    if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
+    if ((int)scene->meshes.size() >= RTW_DEV_MAX_SHAPES) return fail(RTW_ERR_LIMIT, "too many shapes");
+    std::unique_ptr<rtw::HostMesh> m(new rtw::HostMesh());
+    auto copy3 = [](std::vector<rtw::Vec3>& dst, const float* src, int n) {
+        dst.resize((size_t)n);
+        if (n > 0) std::memcpy(dst.data(), src, (size_t)n * 12);
+    };
+    copy3(m->points, positions, n_positions);
+    copy3(m->texcoords, texcoords, n_texcoords);
+    copy3(m->normals, normals, n_normals);
+    m->point_idx.assign(idx_p, idx_p + (size_t)n_tris * 3);
+    m->texcoord_idx.assign(idx_t, idx_t + (size_t)n_tris * 3);
+    m->normal_idx.assign(idx_n, idx_n + (size_t)n_tris * 3);
+    if (tri_material) m->poly_material.assign(tri_material, tri_material + n_tris);
+    else m->poly_material.assign((size_t)n_tris, -1);
+    int max_mat = -1;
+    for (int32_t v : m->poly_material) if (v > max_mat) max_mat = v;
+    if (max_mat >= RTW_MAX_MESH_MATERIALS) return fail(RTW_ERR_LIMIT, "material id too large");
+    m->material_names.resize((size_t)(max_mat + 1));
+    m->texture_paths.resize((size_t)(max_mat + 1));
+    m->textures.resize((size_t)(max_mat + 1));
+    const std::string err = rtw::finish_arrays(*m, shape_bounds6);
+    if (!err.empty()) return fail(RTW_ERR_INVALID, err);
+    scene->meshes.push_back(std::move(m));
+    if (out_shape) *out_shape = (int)scene->meshes.size() - 1;
+    return RTW_OK;
+}
+
+int rtw_scene_set_texture(rtw_scene* scene, int shape, int material_id, const uint8_t* texels, int width, int height, int channels)
+{
+    if (!scene || !texels) return fail(RTW_ERR_INVALID, "null argument");
+    if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
+    if (shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    if (material_id < 0 || material_id >= RTW_MAX_MESH_MATERIALS) return fail(RTW_ERR_INVALID, "bad material id");
+    if (width <= 0 || height <= 0 || (channels != 3 && channels != 4)) return fail(RTW_ERR_INVALID, "bad texture format");
+    rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    if ((int)m.textures.size() <= material_id) { m.textures.resize((size_t)material_id + 1); m.texture_paths.resize((size_t)material_id + 1); }
+    rtw::HostTexture t; t.width = width; t.height = height; t.valid = true;
+    t.rgba8.resize((size_t)width * (size_t)height);
+    for (size_t i = 0; i < t.rgba8.size(); i++) {
+        const uint8_t* s = texels + i * (size_t)channels;
+        t.rgba8[i] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)(channels == 4 ? s[3] : 255) << 24);
+    }
+    m.textures[(size_t)material_id] = std::move(t);
+    // the reference sizes its texture table by the triangle count once an MTL is present
+    if (m.n_textures_slots == 0) m.n_textures_slots = m.n_tris();
+    return RTW_OK;
+}
+
+int rtw_scene_set_material(rtw_scene* scene, int shape, const rtw_material_node* nodes, int n_nodes)
+{
+    if (!scene || !nodes) return fail(RTW_ERR_INVALID, "null argument");
+    if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
+    if (shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    if (n_nodes < 1 || n_nodes > RTW_MAX_MATERIAL_NODES) return fail(RTW_ERR_LIMIT, "material node count out of range");
+    // children after parents; nesting of Combine nodes bounded by the device evaluation stack
+    std::vector<int> combine_depth((size_t)n_nodes, 0);
+    for (int i = 0; i < n_nodes; i++) {
+        const rtw_material_node& n = nodes[i];
+        if (n.type < RTW_MAT_DIFFUSE || n.type > RTW_MAT_NULL) return fail(RTW_ERR_INVALID, "unknown material type");
+        if (n.type == RTW_MAT_BLEND || n.type == RTW_MAT_COMBINE) {
+            if (n.child_a <= i || n.child_a >= n_nodes || n.child_b <= i || n.child_b >= n_nodes)
+                return fail(RTW_ERR_INVALID, "material children must follow their parent");
+            const int d = combine_depth[(size_t)i] + (n.type == RTW_MAT_COMBINE ? 1 : 0);
+            if (d > 2) return fail(RTW_ERR_LIMIT, "Combine nesting deeper than 2");
+            if (d > combine_depth[(size_t)n.child_a]) combine_depth[(size_t)n.child_a] = d;
+            if (d > combine_depth[(size_t)n.child_b]) combine_depth[(size_t)n.child_b] = d;
+        }
+    }
+    rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    m.material.resize((size_t)n_nodes);
+    std::memcpy(m.material.data(), nodes, (size_t)n_nodes * sizeof(rtw_material_node));
+    return RTW_OK;
+}
+
+int rtw_scene_set_prune(rtw_scene* scene, int enabled)
+{
+    if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
+    scene->prune = enabled ? 1 : 0;
+    if (scene->committed && scene->ctx) {
+        HIP_TRY(hipSetDevice(scene->ctx->device));
+        HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+        HIP_TRY(hipMemcpy((char*)scene->d_scene + offsetof(RtwSceneDev, prune), &scene->prune, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return RTW_OK;
+}
+
+int rtw_scene_commit(rtw_scene* scene)
+{
+    if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
+    if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
+    if (!scene->ctx) {      // host-only scene: build the flattened trees for inspection, nothing to upload
+        for (auto& m : scene->meshes) rtw::build_tree(*m);
+        scene->committed = true;
+        return RTW_OK;
+    }
+    HIP_TRY(hipSetDevice(scene->ctx->device));
+    std::unique_ptr<RtwSceneDev> h(new RtwSceneDev());
+    std::memset(h.get(), 0, sizeof(RtwSceneDev));
+    h->n_shapes = (int)scene->meshes.size();
+    h->prune = scene->prune;
+    h->unit_table = scene->ctx->d_unit;
+    h->gamma_thr = scene->ctx->d_gamma;
+    h->texel_lut = scene->ctx->d_lut;
+    h->stats = scene->ctx->d_stats;
+    for (size_t s = 0; s < scene->meshes.size(); s++) {
+        rtw::HostMesh& m = *scene->meshes[s];
+        rtw::build_tree(m);
+        RtwShapeDev& d = h->shapes[s];
+        int rc;
+        if ((rc = upload(scene, m.nodes, &d.nodes)) != RTW_OK) return rc;
+        if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
+        if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
+        std::vector<uint32_t> atlas;
+        for (size_t t = 0; t < m.textures.size() && t < RTW_DEV_MAX_TEXTURES; t++) {
+            const rtw::HostTexture& tx = m.textures[t];
+            if (!tx.valid) continue;
+            d.textures[t].offset = (uint32_t)atlas.size();
+            d.textures[t].width = tx.width; d.textures[t].height = tx.height; d.textures[t].valid = 1;
+            atlas.insert(atlas.end(), tx.rgba8.begin(), tx.rgba8.end());
+        }
+        if ((rc = upload(scene, atlas, &d.texels)) != RTW_OK) return rc;
+        for (int k = 0; k < 3; k++) { d.bmin[k] = m.bmin[k]; d.bmax[k] = m.bmax[k]; }
+        d.n_nodes = (int)m.nodes.size(); d.n_tris = (int)m.tris.size();
+        d.n_textures = m.n_textures_slots;
+        d.has_material = m.material.empty() ? 0 : 1;
+        d.n_material_nodes = (int)m.material.size();
+        for (size_t k = 0; k < m.material.size(); k++) d.material[k] = m.material[k];
+    }
+    void* dsc = nullptr;
+    HIP_TRY(hipMalloc(&dsc, sizeof(RtwSceneDev)));
+    scene->allocs.push_back(dsc);
+    HIP_TRY(hipMemcpy(dsc, h.get(), sizeof(RtwSceneDev), hipMemcpyHostToDevice));
+    scene->d_scene = (RtwSceneDev*)dsc;
+    scene->committed = true;
+    return RTW_OK;
+}
+
+int rtw_scene_mesh_info(const rtw_scene* scene, int shape, int32_t info[8], float shape_bounds6[6])
+{
+    if (!scene || shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    if (info) {
+        info[0] = (int)m.points.size(); info[1] = (int)m.texcoords.size(); info[2] = (int)m.normals.size();
+        info[3] = m.n_tris(); info[4] = (int)m.material_names.size(); info[5] = (int)m.nodes.size();
+        int ntex = 0; for (const auto& t : m.textures) ntex += t.valid ? 1 : 0;
+        info[6] = ntex; info[7] = m.max_depth;
+    }
+    if (shape_bounds6) for (int k = 0; k < 3; k++) { shape_bounds6[k] = m.bmin[k]; shape_bounds6[k + 3] = m.bmax[k]; }
+    return RTW_OK;
+}
+
+int rtw_scene_mesh_nodes(const rtw_scene* scene, int shape, float* bounds6, int32_t* skip, int32_t* tri, int max_nodes)
+{
+    if (!scene || shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
+    const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    const int n = (int)m.nodes.size() < max_nodes ? (int)m.nodes.size() : max_nodes;
+    for (int i = 0; i < n; i++) {
+        const RtwNode& nd = m.nodes[(size_t)i];
+        if (bounds6) { float* b = bounds6 + (size_t)i * 6; b[0] = nd.min_x; b[1] = nd.min_y; b[2] = nd.min_z; b[3] = nd.max_x; b[4] = nd.max_y; b[5] = nd.max_z; }
+        if (skip) skip[i] = nd.skip;
+        if (tri) tri[i] = nd.tri >= 0 ? m.tris[(size_t)nd.tri].orig : -1;
+    }
+    return (int)m.nodes.size();
+}
+
+// ---- ray-level queries ------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+int need_committed(rtw_scene* scene)
+{
+    if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
+    if (!scene->ctx) return fail(RTW_ERR_NO_DEVICE, "host-only scene (created without a context): no device, no CPU fallback");
+    if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
+    hipError_t e = hipSetDevice(scene->ctx->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return RTW_OK;
+}
+}  // namespace
+
+int rtw_trace_closest(rtw_scene* scene, const float* rays, int64_t n, float* hits11, int32_t* shape, int32_t* tri)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (n < 0 || (n > 0 && (!rays || !hits11 || !shape || !tri))) return fail(RTW_ERR_INVALID, "null argument");
+    if (n == 0) return RTW_OK;
+    hipStream_t st = scene->ctx->stream;
+    DevBuf dr, dh, ds, dt;
+    HIP_TRY(dr.alloc((size_t)n * 28)); HIP_TRY(dh.alloc((size_t)n * 44)); HIP_TRY(ds.alloc((size_t)n * 4)); HIP_TRY(dt.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(dr.p, rays, (size_t)n * 28, hipMemcpyHostToDevice, st));
+    hipError_t e = (hipError_t)rtw::launch_closest(scene->d_scene, (const float*)dr.p, n, (float*)dh.p, (int*)ds.p, (int*)dt.p, scene->ctx->stats_enabled, st);
+    if (e != hipSuccess) return hip_fail(e, "closest_kernel launch");
+    HIP_TRY(hipMemcpyAsync(hits11, dh.p, (size_t)n * 44, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(shape, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(tri, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RTW_OK;
+}
+
+int rtw_ray_trace(rtw_scene* scene, const float* rays, const uint32_t* keys2, int64_t n, int max_bounce, int use_base_color,
+                  uint32_t seed, int width, int height, float* rgb)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (n < 0 || (n > 0 && (!rays || !keys2 || !rgb))) return fail(RTW_ERR_INVALID, "null argument");
+    if (max_bounce < 0 || max_bounce > RTW_MAX_BOUNCE) return fail(RTW_ERR_LIMIT, "max_bounce out of range");
+    if (width <= 0 || height <= 0) return fail(RTW_ERR_INVALID, "bad image size");
+    if (n == 0) return RTW_OK;
+    hipStream_t st = scene->ctx->stream;
+    DevBuf dr, dk, dc;
+    HIP_TRY(dr.alloc((size_t)n * 28)); HIP_TRY(dk.alloc((size_t)n * 8)); HIP_TRY(dc.alloc((size_t)n * 12));
+    HIP_TRY(hipMemcpyAsync(dr.p, rays, (size_t)n * 28, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dk.p, keys2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(n, max_bounce)); if (rc != RTW_OK) return rc;
+    hipError_t e = (hipError_t)rtw::launch_ray_trace(scene->d_scene, (const float*)dr.p, (const uint32_t*)dk.p, n, max_bounce, use_base_color, seed,
+                                                     (unsigned long long)width * (unsigned long long)height, (float*)dc.p, scene->ctx->d_workspace,
+                                                     scene->ctx->stats_enabled, st);
+    if (e != hipSuccess) return hip_fail(e, "ray_trace_kernel launch");
+    HIP_TRY(hipMemcpyAsync(rgb, dc.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RTW_OK;
+}
+
+int rtw_texture_sample(rtw_scene* scene, int shape, int material_id, const float* uv, int64_t n, float* rgba)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    if (material_id < 0 || material_id >= (int)m.textures.size() || material_id >= RTW_DEV_MAX_TEXTURES || !m.textures[(size_t)material_id].valid)
+        return fail(RTW_ERR_INVALID, "material has no texture");
+    if (n < 0 || (n > 0 && (!uv || !rgba))) return fail(RTW_ERR_INVALID, "null argument");
+    if (n == 0) return RTW_OK;
+    hipStream_t st = scene->ctx->stream;
+    DevBuf du, dc;
+    HIP_TRY(du.alloc((size_t)n * 8)); HIP_TRY(dc.alloc((size_t)n * 16));
+    HIP_TRY(hipMemcpyAsync(du.p, uv, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipError_t e = (hipError_t)rtw::launch_texture_sample(scene->d_scene, shape, material_id, (const float*)du.p, n, (float*)dc.p, st);
+    if (e != hipSuccess) return hip_fail(e, "texture_sample_kernel launch");
+    HIP_TRY(hipMemcpyAsync(rgba, dc.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RTW_OK;
+}
+
+// ---- framebuffer -------------------------------------------------------------------------------------------
+int rtw_framebuffer_create(rtw_context* ctx, int width, int height, rtw_framebuffer** out)
+{
+    if (!ctx || !out || width <= 0 || height <= 0) return fail(RTW_ERR_INVALID, "bad argument");
+    if ((int64_t)width * height > (int64_t)1 << 30) return fail(RTW_ERR_LIMIT, "framebuffer too large");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<rtw_framebuffer> fb(new rtw_framebuffer());
+    fb->ctx = ctx; fb->width = width; fb->height = height; fb->owned = true;
+    const size_t n = (size_t)width * (size_t)height;
+    HIP_TRY(hipMalloc(&fb->accum, n * 16));
+    HIP_TRY(hipMalloc(&fb->argb, n * 4));
+    HIP_TRY(hipMemsetAsync(fb->accum, 0, n * 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(fb->argb, 0, n * 4, ctx->stream));
+    *out = fb.release();
+    return RTW_OK;
+}
+
+int rtw_framebuffer_wrap(rtw_context* ctx, int width, int height, void* accum_dev, void* argb_dev, rtw_framebuffer** out)
+{
+    if (!ctx || !out || width <= 0 || height <= 0 || !accum_dev || !argb_dev) return fail(RTW_ERR_INVALID, "bad argument");
+    rtw_framebuffer* fb = new rtw_framebuffer();
+    fb->ctx = ctx; fb->width = width; fb->height = height; fb->owned = false;
+    fb->accum = accum_dev; fb->argb = argb_dev;
+    *out = fb;
+    return RTW_OK;
+}
+
+int rtw_framebuffer_destroy(rtw_framebuffer* fb)
+{
+    if (!fb) return RTW_OK;
+    if (fb->owned) {
+        (void)hipSetDevice(fb->ctx->device);
+        (void)hipStreamSynchronize(fb->ctx->stream);
+        (void)hipFree(fb->accum); (void)hipFree(fb->argb);
+    }
+    delete fb;
+    return RTW_OK;
+}
+
+int rtw_framebuffer_clear(rtw_framebuffer* fb)
+{
+    if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
+    HIP_TRY(hipSetDevice(fb->ctx->device));
+    const size_t n = (size_t)fb->width * (size_t)fb->height;
+    HIP_TRY(hipMemsetAsync(fb->accum, 0, n * 16, fb->ctx->stream));
+    HIP_TRY(hipMemsetAsync(fb->argb, 0, n * 4, fb->ctx->stream));
+    return RTW_OK;
+}
+
+int rtw_framebuffer_read_float(rtw_framebuffer* fb, float* accum4)
+{
+    if (!fb || !accum4) return fail(RTW_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(fb->ctx->device));
+    const size_t n = (size_t)fb->width * (size_t)fb->height;
+    HIP_TRY(hipMemcpyAsync(accum4, fb->accum, n * 16, hipMemcpyDeviceToHost, fb->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(fb->ctx->stream));
+    for (size_t i = 0; i < n; i++) {        // the count travels as int bits on the device
+        int32_t c; std::memcpy(&c, &accum4[i * 4 + 3], 4);
+        accum4[i * 4 + 3] = (float)c;
+    }
+    return RTW_OK;
+}
+
+int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb)
+{
+    if (!fb || !argb) return fail(RTW_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(fb->ctx->device));
+    const size_t n = (size_t)fb->width * (size_t)fb->height;
+    HIP_TRY(hipMemcpyAsync(argb, fb->argb, n * 4, hipMemcpyDeviceToHost, fb->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(fb->ctx->stream));
+    return RTW_OK;
+}
+
+// ---- the hot path -------------------------------------------------------------------------------------------
+static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams& p, int max_bounce, int use_base_color,
+                         int pass_index, int sub_samples, uint32_t seed)
+{
+    if (fb->ctx != scene->ctx) return fail(RTW_ERR_INVALID, "scene and framebuffer belong to different contexts");
+    if (max_bounce < 0 || max_bounce > RTW_MAX_BOUNCE) return fail(RTW_ERR_LIMIT, "max_bounce out of range");
+    if (sub_samples < 1 || sub_samples > 4) return fail(RTW_ERR_INVALID, "sub_samples must be 1..4");
+    if (pass_index < 0) return fail(RTW_ERR_INVALID, "pass_index must be >= 0");
+    p.width = fb->width; p.height = fb->height;
+    p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
+    int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
+    hipError_t e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "render_kernel launch");
+    return RTW_OK;
+}
+
+int rtw_render_range(rtw_scene* scene, rtw_framebuffer* fb, int begin, int end, int max_bounce, int use_base_color,
+                     int pass_index, int sub_samples, uint32_t seed)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
+    const int npix = fb->width * fb->height;
+    if (begin < 0 || end >= npix) return fail(RTW_ERR_INVALID, "pixel range outside the framebuffer");
+    RtwRenderParams p; std::memset(&p, 0, sizeof p);
+    p.begin = begin; p.count = end >= begin ? end - begin + 1 : 0;      // an empty range renders nothing, like the reference loop
+    p.task_rows = 0; p.rank = 0; p.world = 1;
+    return render_common(scene, fb, p, max_bounce, use_base_color, pass_index, sub_samples, seed);
+}
+
+int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world, int max_bounce, int use_base_color,
+                     int pass_index, int sub_samples, uint32_t seed)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
+    if (task_rows < 1 || world < 1 || rank < 0 || rank >= world) return fail(RTW_ERR_INVALID, "bad task partition");
+    RtwRenderParams p; std::memset(&p, 0, sizeof p);
+    const int n_tasks = (fb->height + task_rows - 1) / task_rows;
+    const int mine = n_tasks > rank ? (n_tasks - rank + world - 1) / world : 0;
+    p.begin = 0; p.task_rows = task_rows; p.rank = rank;
+    p.world = world;
+    if (world == 1) { p.count = fb->width * fb->height; }
+    else {
+        const int64_t cnt = (int64_t)mine * task_rows * fb->width;
+        if (cnt > INT32_MAX) return fail(RTW_ERR_LIMIT, "too many work items");
+        p.count = (int)cnt;
+    }
+    return render_common(scene, fb, p, max_bounce, use_base_color, pass_index, sub_samples, seed);
+}
+
+// ---- stats ------------------------------------------------------------------------------------------------------
+int rtw_stats_enable(rtw_context* ctx, int enabled)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    ctx->stats_enabled = enabled != 0;
+    return RTW_OK;
+}
+int rtw_stats_reset(rtw_context* ctx)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    return RTW_OK;
+}
+int rtw_stats_get(rtw_context* ctx, rtw_stats* out)
+{
+    if (!ctx || !out) return fail(RTW_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+#ifdef RTW_BOUNDS_DEBUG
+    std::fprintf(stderr, "RTW_BOUNDS_DEBUG: site=%llu value=%lld\n", h[6], (long long)h[7]);
+#endif
+    out->rays = h[0]; out->box_tests = h[1]; out->tri_tests = h[2]; out->shaded_hits = h[3]; out->tex_samples = h[4]; out->camera_rays = h[5];
+    return RTW_OK;
+}
+
+// ---- tables + file helpers (host only, no device needed) ------------------------------------------------------------
+uint32_t rtw_rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter) { return rtw::rand31(seed, pixel, sample, counter); }
+int rtw_unit_table_entry(uint32_t index, float out3[3])
+{
+    if (!out3 || index >= RTW_TABLE_SIZE) return fail(RTW_ERR_INVALID, "bad table index");
+    rtw::unit_table_entry(index, out3);
+    return RTW_OK;
+}
+int rtw_gamma_thresholds(float out256[256]) { if (!out256) return fail(RTW_ERR_INVALID, "null"); rtw::gamma_thresholds(out256); return RTW_OK; }
+int rtw_texel_lut(float out256[256]) { if (!out256) return fail(RTW_ERR_INVALID, "null"); rtw::texel_lut(out256); return RTW_OK; }
+
+int rtw_png_load(const char* path, uint8_t** texels_out, int* width, int* height, int* channels)
+{
+    if (!path || !texels_out || !width || !height || !channels) return fail(RTW_ERR_INVALID, "null argument");
+    std::vector<uint8_t> px; int w = 0, h = 0, c = 0;
+    const std::string err = rtw::png_load(path, px, w, h, c);
+    if (!err.empty()) return fail(RTW_ERR_IO, err);
+    uint8_t* out = (uint8_t*)std::malloc(px.size() ? px.size() : 1);
+    if (!out) return fail(RTW_ERR_IO, "out of memory");
+    std::memcpy(out, px.data(), px.size());
+    *texels_out = out; *width = w; *height = h; *channels = c;
+    return RTW_OK;
+}
+void rtw_png_free(uint8_t* texels) { std::free(texels); }
+
+int rtw_png_save_argb(const char* path, const uint32_t* argb, int width, int height)
+{
+    if (!path || !argb || width <= 0 || height <= 0) return fail(RTW_ERR_INVALID, "bad argument");
+    std::vector<uint8_t> rgb((size_t)width * (size_t)height * 3);
+    for (size_t i = 0; i < (size_t)width * (size_t)height; i++) {     // GetUint32ColorRed/Green/Blue (Src/ColorBuffer.h:43-68)
+        rgb[i * 3] = (uint8_t)((argb[i] >> 16) & 0xFF); rgb[i * 3 + 1] = (uint8_t)((argb[i] >> 8) & 0xFF); rgb[i * 3 + 2] = (uint8_t)(argb[i] & 0xFF);
+    }
+    const std::string err = rtw::png_save_rgb(path, rgb.data(), width, height);
+    if (!err.empty()) return fail(RTW_ERR_IO, err);
+    return RTW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+// scene_host.cpp -- host-side scene library: OBJ/MTL loading with the reference parser's
+// observable semantics, the reference's split decisions for the one-triangle-per-leaf
+// bounding tree flattened to a stack-free preorder array, and the host-generated tables
+// the kernels read (unit vectors, gamma thresholds, texel LUT).
+//
+// Build with -ffp-contract=off: split decisions, face normals and table entries must be
+// the same bits the reference computes (Src/KdTree.cpp:37-126, Src/RRay.cpp:138-145,
+// Src/Math.h:34-40).
+#include "rtw_host.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <thread>
+
+namespace rtw {
+
+namespace {
+
+inline Vec3 sub(Vec3 a, Vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline Vec3 add(Vec3 a, Vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline Vec3 cross(Vec3 a, Vec3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline bool near_zero(float a) { return std::fabs(a) < FLT_EPSILON; }   // FLT_EQUAL_ZERO, Src/MathHelper.h:12
+
+// RVec3::GetNormalizedVec3 (Src/RVector.h:169-183): tiny vectors are returned un-normalised
+inline Vec3 normalized(Vec3 v)
+{
+    float sq = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (!near_zero(sq)) {
+        float inv = 1.0f / std::sqrt(sq);
+        v.x *= inv; v.y *= inv; v.z *= inv;
+    }
+    return v;
+}
+
+// --- line tokenising ------------------------------------------------------------------
+// "keyword" = text before the first blank (Src/MeshShape.cpp:23-36)
+std::string keyword_of(const std::string& line)
+{
+    size_t sp = line.find(' ');
+    return sp == std::string::npos ? line : line.substr(0, sp);
+}
+// fields separated by ONE blank each; a trailing blank does not open an empty field
+// (std::getline semantics of Src/MeshShape.cpp:50-62)
+std::vector<std::string> blank_fields(const std::string& line)
+{
+    std::vector<std::string> out;
+    size_t pos = 0;
+    while (pos < line.size()) {
+        size_t sp = line.find(' ', pos);
+        if (sp == std::string::npos) { out.push_back(line.substr(pos)); break; }
+        out.push_back(line.substr(pos, sp - pos));
+        pos = sp + 1;
+    }
+    return out;
+}
+// whitespace-delimited reader for the numeric lines (operator>> semantics)
+struct Cursor {
+    const char* p;
+    explicit Cursor(const std::string& s) : p(s.c_str()) {}
+    void skip_word() { while (*p == ' ' || *p == '\t') p++; while (*p && *p != ' ' && *p != '\t') p++; }
+    float number() { char* e; float v = std::strtof(p, &e); if (e == p) return 0.0f; p = e; return v; }
+    std::string word()
+    {
+        while (*p == ' ' || *p == '\t') p++;
+        const char* b = p;
+        while (*p && *p != ' ' && *p != '\t' && *p != '\r') p++;
+        return std::string(b, p);
+    }
+};
+// k-th integer of a "p/t/n" vertex reference (Src/MeshShape.cpp:38-48)
+int slash_field(const std::string& tok, int k)
+{
+    const char* p = tok.c_str();
+    int value = -1;
+    for (int i = 0; i <= k; i++) {
+        char* e; long v = std::strtol(p, &e, 10);
+        if (e == p) return 0;          // failed extraction leaves 0
+        value = (int)v; p = e;
+        if (!*p) { if (i < k) return value; break; }
+        p++;                            // the separator
+    }
+    return value;
+}
+
+bool open_with_parent_fallback(const std::string& name, std::ifstream& f, std::string& resolved)
+{
+    resolved = name;
+    f.open(resolved, std::ios::binary);
+    for (int i = 0; !f.is_open() && i < 2; i++) {       // Src/MeshShape.cpp:70-83
+        resolved = "../" + resolved;
+        f.clear(); f.open(resolved, std::ios::binary);
+    }
+    return f.is_open();
+}
+
+}  // namespace
+
+std::string load_obj(const std::string& path, HostMesh& m)
+{
+    std::ifstream f; std::string resolved;
+    if (!open_with_parent_fallback(path, f, resolved)) return "unable to open " + path;
+
+    int current = -1;
+    std::string line;
+    while (std::getline(f, line)) {
+        const std::string key = keyword_of(line);
+        if (key == "v" || key == "vn") {
+            Cursor c(line); c.skip_word();
+            Vec3 v; v.x = c.number(); v.y = c.number(); v.z = c.number();
+            (key == "v" ? m.points : m.normals).push_back(v);
+        } else if (key == "vt") {
+            Cursor c(line); c.skip_word();
+            Vec3 v; v.x = c.number(); v.y = c.number(); v.z = 0.0f;
+            m.texcoords.push_back(v);
+        } else if (key == "f") {
+            const std::vector<std::string> fld = blank_fields(line);
+            const int corners = (int)fld.size() - 1;
+            static const int fan3[3] = { 0, 1, 2 }, fan4[6] = { 0, 1, 2, 0, 2, 3 };   // quad -> (0,1,2),(0,2,3)
+            const int* order = corners == 3 ? fan3 : corners == 4 ? fan4 : nullptr;
+            const int n = corners == 3 ? 3 : corners == 4 ? 6 : 0;                  // other polygons are dropped
+            for (int i = 0; i < n; i++) {
+                const std::string& ref = fld[(size_t)order[i] + 1];
+                m.point_idx.push_back(slash_field(ref, 0) - 1);
+                m.texcoord_idx.push_back(slash_field(ref, 1) - 1);
+                m.normal_idx.push_back(slash_field(ref, 2) - 1);
+                if (i % 3 == 0) m.poly_material.push_back(current);
+            }
+        } else if (key == "usemtl") {
+            const std::vector<std::string> fld = blank_fields(line);
+            const std::string name = fld.size() > 1 ? fld[1] : std::string();
+            current = -1;
+            for (size_t i = 0; i < m.material_names.size(); i++) if (m.material_names[i] == name) { current = (int)i; break; }
+            if (current < 0) { m.material_names.push_back(name); current = (int)m.material_names.size() - 1; }
+        }
+    }
+    f.close();
+    m.texture_paths.assign(m.material_names.size(), std::string());
+    m.textures.assign(m.material_names.size(), HostTexture());
+
+    // sibling .mtl: newmtl / map_Kd only (Src/MeshShape.cpp:202-272)
+    std::string mtl = resolved;
+    size_t ext = mtl.find(".obj");
+    if (ext != std::string::npos) {
+        mtl.replace(ext, 4, ".mtl");
+        std::ifstream mf(mtl, std::ios::binary);
+        if (mf.is_open()) {
+            std::string base;
+            size_t slash = mtl.find_last_of("\\/");
+            if (slash != std::string::npos) base = mtl.substr(0, slash + 1);
+            m.n_textures_slots = m.n_tris();           // Textures.resize(PolyMaterialId.size())
+            current = -1;
+            while (std::getline(mf, line)) {
+                const std::string key = keyword_of(line);
+                if (key == "newmtl") {
+                    Cursor c(line); c.skip_word();
+                    const std::string name = c.word();
+                    current = -1;
+                    for (size_t i = 0; i < m.material_names.size(); i++) if (m.material_names[i] == name) { current = (int)i; break; }
+                } else if (key == "map_Kd" && current != -1) {
+                    Cursor c(line); c.skip_word();
+                    std::string tex = base + c.word();
+                    for (size_t bs = tex.find("\\\\"); bs != std::string::npos; bs = tex.find("\\\\")) tex.replace(bs, 2, "/");
+                    m.texture_paths[(size_t)current] = tex;
+                    std::vector<uint8_t> px; int w = 0, h = 0, ch = 0;
+                    HostTexture t;
+                    if (png_load(tex, px, w, h, ch).empty()) {      // a bad PNG degrades to "no texture" (Src/Texture.cpp:161-196)
+                        t.width = w; t.height = h; t.valid = true;
+                        t.rgba8.resize((size_t)w * (size_t)h);
+                        for (size_t i = 0; i < t.rgba8.size(); i++) {
+                            const uint8_t* s = &px[i * (size_t)ch];
+                            t.rgba8[i] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)(ch == 4 ? s[3] : 255) << 24);
+                        }
+                    }
+                    m.textures[(size_t)current] = std::move(t);
+                }
+            }
+        }
+    }
+    return finish_arrays(m, nullptr);
+}
+
+std::string finish_arrays(HostMesh& m, const float* bounds6)
+{
+    const size_t nv = m.point_idx.size();
+    if (nv % 3 != 0 || m.texcoord_idx.size() != nv || m.normal_idx.size() != nv || m.poly_material.size() != nv / 3)
+        return "inconsistent index array sizes";
+    for (size_t i = 0; i < nv; i++) {
+        // the reference would index out of bounds here; the library refuses the mesh instead
+        if (m.point_idx[i] < 0 || m.point_idx[i] >= (int)m.points.size()) return "position index out of range";
+        if (m.texcoord_idx[i] < 0 || m.texcoord_idx[i] >= (int)m.texcoords.size()) return "texcoord index out of range";
+        if (m.normal_idx[i] < 0 || m.normal_idx[i] >= (int)m.normals.size()) return "normal index out of range";
+    }
+    for (size_t i = 0; i < nv / 3; i++)
+        if (m.poly_material[i] < -1 || m.poly_material[i] >= RTW_DEV_MAX_TEXTURES) return "material id out of range";
+    if (bounds6) {
+        for (int k = 0; k < 3; k++) { m.bmin[k] = bounds6[k]; m.bmax[k] = bounds6[k + 3]; }
+    } else {
+        // RShape::Aabb grows over every `v` line, referenced or not (Src/MeshShape.cpp:109)
+        for (int k = 0; k < 3; k++) { m.bmin[k] = FLT_MAX; m.bmax[k] = -FLT_MAX; }
+        for (const Vec3& p : m.points) {
+            const float c[3] = { p.x, p.y, p.z };
+            for (int k = 0; k < 3; k++) { if (c[k] < m.bmin[k]) m.bmin[k] = c[k]; if (c[k] > m.bmax[k]) m.bmax[k] = c[k]; }
+        }
+    }
+    if (m.textures.size() < m.material_names.size()) m.textures.resize(m.material_names.size());
+    return std::string();
+}
+
+// ---------------------------------------------------------------------------------------
+// tree: the reference's recursion (bounds of the node's vertices; leaf iff one triangle;
+// split at the mean centroid along the largest extent, strict '<' goes left; a one-sided
+// split falls back to first half / second half of the current order), emitted in preorder.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct BuildRef { int32_t a, b, c, index; };
+
+struct TreeBuilder {
+    HostMesh& m;
+    int deepest = 0;
+    explicit TreeBuilder(HostMesh& mesh) : m(mesh) {}
+
+    static int split_axis(const float lo[3], const float hi[3])
+    {
+        const float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+        if (sx > sy) return sx > sz ? 0 : 2;     // Src/KdTree.cpp:13-34 (ties go to Z, then Y)
+        return sy > sz ? 1 : 2;
+    }
+    Vec3 centroid(const BuildRef& t) const
+    {
+        const Vec3 s = add(add(m.points[(size_t)t.a], m.points[(size_t)t.b]), m.points[(size_t)t.c]);
+        return { s.x / 3.0f, s.y / 3.0f, s.z / 3.0f };
+    }
+
+    void emit(const std::vector<BuildRef>& refs, int depth)
+    {
+        if (depth > deepest) deepest = depth;
+        const size_t self = m.nodes.size();
+        m.nodes.emplace_back();
+        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        for (const BuildRef& t : refs) {
+            for (int32_t vi : { t.a, t.b, t.c }) {
+                const Vec3& p = m.points[(size_t)vi];
+                const float c[3] = { p.x, p.y, p.z };
+                for (int k = 0; k < 3; k++) { if (c[k] < lo[k]) lo[k] = c[k]; if (c[k] > hi[k]) hi[k] = c[k]; }
+            }
+        }
+        RtwNode nd;
+        nd.min_x = lo[0]; nd.min_y = lo[1]; nd.min_z = lo[2];
+        nd.max_x = hi[0]; nd.max_y = hi[1]; nd.max_z = hi[2];
+        nd.tri = -1; nd.skip = 0;
+
+        if (refs.size() == 1) {
+            nd.tri = (int32_t)m.tris.size();
+            add_leaf_records(refs[0]);
+        } else {
+            Vec3 mean = { 0, 0, 0 };
+            for (const BuildRef& t : refs) mean = add(mean, centroid(t));
+            const float n = (float)refs.size();
+            mean.x /= n; mean.y /= n; mean.z /= n;
+            const int axis = split_axis(lo, hi);
+            const float cut = axis == 0 ? mean.x : axis == 1 ? mean.y : mean.z;
+            std::vector<BuildRef> left, right;
+            for (const BuildRef& t : refs) {
+                const Vec3 c = centroid(t);
+                const float v = axis == 0 ? c.x : axis == 1 ? c.y : c.z;
+                (v < cut ? left : right).push_back(t);
+            }
+            if (left.size() == refs.size() || right.size() == refs.size()) {
+                const size_t half = refs.size() / 2;
+                left.assign(refs.begin(), refs.begin() + (long)half);
+                right.assign(refs.begin() + (long)half, refs.end());
+            }
+            if (!left.empty()) emit(left, depth + 1);
+            if (!right.empty()) emit(right, depth + 1);
+        }
+        nd.skip = (int32_t)m.nodes.size();
+        m.nodes[self] = nd;
+    }
+
+    void add_leaf_records(const BuildRef& t)
+    {
+        const Vec3 p0 = m.points[(size_t)t.a], p1 = m.points[(size_t)t.b], p2 = m.points[(size_t)t.c];
+        // the reference recomputes this per test (Src/RRay.cpp:138-145); it only depends on the triangle
+        const Vec3 n = normalized(cross(sub(p1, p0), sub(p2, p0)));
+        RtwTri r;
+        r.p0x = p0.x; r.p0y = p0.y; r.p0z = p0.z; r.nx = n.x;
+        r.p1x = p1.x; r.p1y = p1.y; r.p1z = p1.z; r.ny = n.y;
+        r.p2x = p2.x; r.p2y = p2.y; r.p2z = p2.z; r.nz = n.z;
+        r.d1 = dot(n, p0); r.orig = t.index; r.pad0 = r.pad1 = 0;
+        m.tris.push_back(r);
+        const size_t v = (size_t)t.index * 3;
+        const Vec3 n0 = m.normals[(size_t)m.normal_idx[v]], n1 = m.normals[(size_t)m.normal_idx[v + 1]], n2 = m.normals[(size_t)m.normal_idx[v + 2]];
+        const Vec3 t0 = m.texcoords[(size_t)m.texcoord_idx[v]], t1 = m.texcoords[(size_t)m.texcoord_idx[v + 1]], t2 = m.texcoords[(size_t)m.texcoord_idx[v + 2]];
+        RtwShade s;
+        s.n0x = n0.x; s.n0y = n0.y; s.n0z = n0.z; s.n1x = n1.x; s.n1y = n1.y; s.n1z = n1.z; s.n2x = n2.x; s.n2y = n2.y; s.n2z = n2.z;
+        s.u0 = t0.x; s.v0 = t0.y; s.u1 = t1.x; s.v1 = t1.y; s.u2 = t2.x; s.v2 = t2.y;
+        s.material = m.poly_material[(size_t)t.index];
+        m.shade.push_back(s);
+    }
+};
+
+}  // namespace
+
+void build_tree(HostMesh& m)
+{
+    m.nodes.clear(); m.tris.clear(); m.shade.clear(); m.max_depth = 0;
+    const int n = m.n_tris();
+    if (n == 0) return;
+    std::vector<BuildRef> all((size_t)n);
+    for (int i = 0; i < n; i++) all[(size_t)i] = { m.point_idx[(size_t)i * 3], m.point_idx[(size_t)i * 3 + 1], m.point_idx[(size_t)i * 3 + 2], i };
+    m.nodes.reserve((size_t)2 * (size_t)n);
+    TreeBuilder b(m);
+    b.emit(all, 1);
+    m.max_depth = b.deepest;
+}
+
+// ---------------------------------------------------------------------------------------
+// random stream + host-generated tables
+// ---------------------------------------------------------------------------------------
+namespace {
+inline uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+inline uint32_t stream_key(uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint32_t h = mix32(seed ^ 0x9E3779B9u);
+    h = mix32(h + pixel);
+    return mix32(h + sample);
+}
+inline float uniform_from(uint32_t r31) { return (float)(int32_t)r31 / 2147483648.0f; }   // (float)rand() / RAND_MAX
+}  // namespace
+
+uint32_t rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter)
+{
+    return mix32(stream_key(seed, pixel, sample) + counter) >> 1;
+}
+
+// entry i of the table RMath::InitPseudoRandomUnitVector would fill (Src/Math.cpp:24-31,
+// Src/Math.h:34-40) when the 2i-th and (2i+1)-th rand() calls return the table stream's draws
+void unit_table_entry(uint32_t index, float out3[3])
+{
+    const uint32_t key = stream_key(RTW_TABLE_SEED, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    const float r1 = uniform_from(mix32(key + 2u * index) >> 1);
+    const float r2 = uniform_from(mix32(key + 2u * index + 1u) >> 1);
+    const float t1 = 2.0f * 3.1415926f * r1;
+    const float t2 = acosf(1.0f - 2.0f * r2);
+    const float sin_t2 = sinf(t2);
+    out3[0] = sinf(t1) * sin_t2;
+    out3[1] = cosf(t1) * sin_t2;
+    out3[2] = cosf(t2);
+}
+
+void fill_unit_table(float* dst, int threads)
+{
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    const uint32_t n = RTW_TABLE_SIZE;
+    for (int t = 0; t < threads; t++) {
+        pool.emplace_back([=]() {
+            const uint32_t lo = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)threads);
+            const uint32_t hi = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)threads);
+            for (uint32_t i = lo; i < hi; i++) unit_table_entry(i, dst + (size_t)i * 3);
+        });
+    }
+    for (auto& th : pool) th.join();
+}
+
+// MakePixelColor(LinearToGamma(c)) (Src/ColorBuffer.h:81-109) is a monotone staircase in c;
+// thr[k] = smallest float whose 8-bit value is >= k.  The device resolves a channel with an
+// 8-step search in this table instead of calling a device powf that would not match libm.
+void gamma_thresholds(float out[256])
+{
+    const float exponent = 1.0f / 2.2f;
+    out[0] = 0.0f;
+    for (int k = 1; k < 256; k++) {
+        uint32_t lo = 0, hi; float one = 1.0f; std::memcpy(&hi, &one, 4);
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            float c; std::memcpy(&c, &mid, 4);
+            const int q = (int)(powf(c, exponent) * 255);
+            if (q >= k) hi = mid; else lo = mid;
+        }
+        std::memcpy(&out[k], &hi, 4);
+    }
+}
+
+// GammaToLinear of an 8-bit channel (Src/Texture.cpp:129-131, Src/ColorBuffer.h:70-78)
+void texel_lut(float out[256])
+{
+    for (int i = 0; i < 256; i++) out[i] = powf((float)i / 255, 2.2f);
+}
+
+}  // namespace rtw

@@ -1,0 +1,294 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors from the real reference,
+against the CPU oracle on seeded inputs, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Integer/index outputs and every float output except the
+fuzzy-reflection frames are compared BIT-EXACTLY; the tolerance for the rest is written in place."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, asset
+
+pytestmark = pytest.mark.gpu
+
+import raytracerwin_amd as R  # noqa: E402
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def same(a, b):
+    """bit-identical, except that any NaN equals any NaN (payload/sign of a NaN is not specified)"""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return bool(((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = R.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_scene(ctx, mesh, material):
+    s = R.RayTracerScene(ctx)
+    s.AddShape(R.RMeshShape.Create(asset(mesh + ".obj")), material)
+    s.commit()
+    return s
+
+
+def render_frame(ctx, scene, W, H, ns, depth, preview, seed, pass0=0, npass=1):
+    fb = R.Framebuffer(ctx, W, H)
+    for p in range(pass0, pass0 + npass):
+        R.ThreadWorker_Render(scene, fb, 0, W * H - 1, depth, R.RenderOption(bool(preview)), p, ns, seed)
+    return fb.read_float(), fb.resolve_argb()
+
+
+MESHES = ["TorusKnot", "BlenderMonkey", "unitychan"]
+
+
+@pytest.mark.parametrize("name", MESHES)
+@pytest.mark.parametrize("prune", [0, 1])
+def test_closest_hit_bit_exact_vs_reference_golden(ctx, name, prune):
+    g = np.load(os.path.join(GOLDEN, "closest_%s.npz" % name))
+    s = gpu_scene(ctx, name, R.SurfaceMaterial_Diffuse())
+    s.set_prune(prune)
+    hits, shape, tri = s.FindIntersectionWithScene(g["rays"])
+    assert (shape == g["shape"]).all()
+    hit = shape >= 0
+    assert (tri[hit] == g["tri"][hit]).all()
+    assert (bits(hits[hit]) == bits(g["hit"][hit])).all()
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_closest_hit_bit_exact_vs_oracle_large_batch(ctx, oracle_mod, name):
+    """Fresh seeded rays (camera, interior, axis-parallel, near-epsilon, NaN/inf) vs the oracle."""
+    from tests.golden.make_golden import make_rays
+    os_ = oracle_mod.Scene()
+    sh = os_.add_mesh_obj(asset(name + ".obj"))
+    rng = np.random.default_rng(99)
+    rays = make_rays(os_.shape_bounds(sh), 1500 if name == "unitychan" else 6000, rng)
+    odd = rays[:8].copy()
+    odd[0, 3] = np.nan
+    odd[1, 5] = np.nan
+    odd[2, 0] = np.inf
+    odd[3, 3:6] = 0
+    odd[4, 6] = 0
+    odd[5, 6] = -1
+    odd[6, 4] = 1e-8
+    odd[7, 3] = np.inf
+    s = gpu_scene(ctx, name, R.SurfaceMaterial_Diffuse())
+    if name == "unitychan":
+        # NaN rays reach RTexture::Sample with NaN uv: out-of-bounds reads in the reference (and in the oracle).
+        # The GPU path must survive them; there is nothing defined to compare against.
+        s.FindIntersectionWithScene(odd)
+    else:
+        rays = np.concatenate([rays, odd])
+    of, oshape, otri = os_.trace_closest(rays)
+    for prune in (0, 1):
+        s.set_prune(prune)
+        hits, shape, tri = s.FindIntersectionWithScene(rays)
+        assert (shape == oshape).all()
+        hit = shape >= 0
+        assert (tri[hit] == otri[hit]).all()
+        assert same(hits[hit], of[hit])
+
+
+@pytest.mark.parametrize("mat", [0, 4])
+def test_texture_sample_bit_exact(ctx, mat):
+    g = np.load(os.path.join(GOLDEN, "texsample_unitychan_m%d.npz" % mat))
+    s = gpu_scene(ctx, "unitychan", R.SurfaceMaterial_Diffuse())
+    out = s.texture_sample(0, mat, g["uv"])
+    assert (bits(out) == bits(g["rgba"])).all()
+
+
+FRAMES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "frame_*.npz")))
+FUZZY = {"torus_blendfuzz_d6", "monkey_blendfuzz_d6"}
+
+
+@pytest.mark.parametrize("tag", FRAMES)
+def test_frame_vs_reference_golden(ctx, tag):
+    g = np.load(os.path.join(GOLDEN, "frame_%s.npz" % tag))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    s = gpu_scene(ctx, str(g["mesh"]), R.material_nodes_from_array(g["material"]))
+    accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
+    if tag in FUZZY:
+        # fuzzy reflection: the device evaluates sin/cos/acos in double (not libm's float routines), so a
+        # direction may differ in its last bit; tolerance 1e-4 per channel on >= 99.5 % of the pixels
+        d = np.abs(accum[:, :3] - g["accum"][:, :3]).max(axis=1)
+        assert (d <= 1e-4).mean() >= 0.995
+        assert (accum[:, 3] == g["accum"][:, 3]).all()
+        return
+    assert (argb == g["argb"]).all()
+    if not preview:
+        assert (bits(accum) == bits(g["accum"])).all()
+
+
+@pytest.mark.parametrize("tag", ["torus_blendfuzz_d6", "monkey_blendfuzz_d6"])
+def test_fuzzy_frames_bit_exact_vs_oracle_f64_mode(ctx, oracle_mod, tag):
+    """With the oracle's transcendental mode switched to the device's (double sin/cos/acos), even the
+    fuzzy-reflection frames must agree bit for bit."""
+    O = oracle_mod
+    g = np.load(os.path.join(GOLDEN, "frame_%s.npz" % tag))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset(str(g["mesh"]) + ".obj"))
+    os_.set_material(sh, g["material"])
+    os_.set_unitvec_mode(O.UNITVEC_F64)
+    ofb = O.Framebuffer(W, H)
+    for p in range(pass0, pass0 + npass):
+        os_.render_range(ofb, 0, W * H - 1, depth, False, p, ns, seed)
+    oa, ob = ofb.read()
+    s = gpu_scene(ctx, str(g["mesh"]), R.material_nodes_from_array(g["material"]))
+    accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
+    assert (bits(accum) == bits(oa)).all()
+    assert (argb == ob).all()
+
+
+@pytest.mark.parametrize("tag", ["unitychan_diffuse", "monkey_blendfuzz"])
+def test_ray_trace_vs_reference_golden(ctx, tag):
+    g = np.load(os.path.join(GOLDEN, "raytrace_%s.npz" % tag))
+    depth, seed, W, H = [int(v) for v in g["params"]]
+    s = gpu_scene(ctx, str(g["mesh"]), R.material_nodes_from_array(g["material"]))
+    rgb = s.RayTrace(g["rays"], g["keys"], depth, None, seed, W, H)
+    if tag == "monkey_blendfuzz":
+        d = np.abs(rgb - g["rgb"]).max(axis=1)       # tolerance 1e-4 (double vs libm transcendentals)
+        assert (d <= 1e-4).mean() >= 0.995
+    else:
+        assert (bits(rgb) == bits(g["rgb"])).all()
+
+
+def test_config1_torus_256_depth1_vs_oracle(ctx, oracle_mod):
+    """BASELINE configs[0]: TorusKnot 256x256, 1 spp, depth 1."""
+    O = oracle_mod
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("TorusKnot.obj"))
+    os_.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+    ofb = O.Framebuffer(256, 256)
+    os_.render_pass_pool(ofb, 1, False, 0, 1, 12345, threads=0, task_rows=10)
+    oa, ob = ofb.read()
+    s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Diffuse())
+    accum, argb = render_frame(ctx, s, 256, 256, 1, 1, 0, 12345)
+    assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
+
+
+def test_config2_band_vs_oracle_and_stats(ctx, oracle_mod):
+    """BASELINE configs[1] (TorusKnot 1080p, 1 spp, depth 4): the centre band of rows against the
+    oracle bit for bit, with reference-faithful work counters equal on both sides."""
+    O = oracle_mod
+    W, H = 1920, 1080
+    r0, r1 = 500, 580
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("TorusKnot.obj"))
+    os_.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+    ofb = O.Framebuffer(W, H)
+    O.stats_reset()
+    os_.render_range(ofb, r0 * W, r1 * W - 1, 4, False, 0, 1, 12345)
+    ostats = O.stats_get()
+    oa, ob = ofb.read()
+    s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Diffuse())
+    s.set_prune(0)
+    ctx.stats_enable(True)
+    ctx.stats_reset()
+    fb = R.Framebuffer(ctx, W, H)
+    R.ThreadWorker_Render(s, fb, r0 * W, r1 * W - 1, 4, None, 0, 1, 12345)
+    accum, argb = fb.read_float(), fb.resolve_argb()
+    gstats = ctx.stats()
+    ctx.stats_enable(False)
+    sl = slice(r0 * W, r1 * W)
+    assert (bits(accum[sl]) == bits(oa[sl])).all() and (argb[sl] == ob[sl]).all()
+    assert (accum[:r0 * W] == 0).all() and (accum[r1 * W:] == 0).all()
+    assert gstats == ostats
+
+
+@pytest.mark.parametrize("mesh,mat,ns,depth", [("TorusKnot", "diffuse", 1, 4), ("BlenderMonkey", "blend", 4, 6),
+                                               ("unitychan", "diffuse", 4, 4)])
+def test_full_size_properties(ctx, mesh, mat, ns, depth):
+    """1920x1080 (configs 2-4): (a) pruned traversal == reference-order traversal bit for bit;
+    (b) any split into disjoint ThreadWorker_Render ranges == one full-frame call; (c) row tasks dealt
+    to 1, 2, 3 ranks give the same image; (d) rendering twice is deterministic."""
+    W, H = 1920, 1080
+    material = R.SurfaceMaterial_Diffuse() if mat == "diffuse" else \
+        R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((1, 1, 1), 0.2), R.SurfaceMaterial_Diffuse(), 0.5)
+    s = gpu_scene(ctx, mesh, material)
+    s.set_prune(1)
+    a1, b1 = render_frame(ctx, s, W, H, ns, depth, 0, 777)
+    a2, b2 = render_frame(ctx, s, W, H, ns, depth, 0, 777)
+    assert (bits(a1) == bits(a2)).all() and (b1 == b2).all()
+    s.set_prune(0)
+    a0, b0 = render_frame(ctx, s, W, H, ns, depth, 0, 777)
+    assert (bits(a1) == bits(a0)).all() and (b1 == b0).all()
+    s.set_prune(1)
+    fb = R.Framebuffer(ctx, W, H)
+    cuts = [0, 1, 1919, 1920, 400000, 400001, 1234567, W * H]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        R.ThreadWorker_Render(s, fb, lo, hi - 1, depth, None, 0, ns, 777)
+    assert (bits(fb.read_float()) == bits(a1)).all() and (fb.resolve_argb() == b1).all()
+    for world in (2, 3):
+        fbw = R.Framebuffer(ctx, W, H)
+        for rank in range(world):
+            s.render_tasks(fbw, 10, rank, world, depth, None, 0, ns, 777)
+        assert (bits(fbw.read_float()) == bits(a1)).all() and (fbw.resolve_argb() == b1).all()
+    assert (a1[:, 3] == 1).all()
+    assert np.isfinite(a1[:, :3]).all()
+
+
+def test_accumulation_over_passes_and_empty_range(ctx, oracle_mod):
+    O = oracle_mod
+    W, H = 160, 90
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("BlenderMonkey.obj"))
+    os_.set_material(sh, [(O.MAT_DIFFUSE, (0.9, 0.8, 0.7), 0, 0, 0)])
+    ofb = O.Framebuffer(W, H)
+    for p in range(4):
+        os_.render_range(ofb, 0, W * H - 1, 8, False, p, 4, 5)
+    oa, ob = ofb.read()
+    s = gpu_scene(ctx, "BlenderMonkey", R.SurfaceMaterial_Diffuse((0.9, 0.8, 0.7)))
+    fb = R.Framebuffer(ctx, W, H)
+    for p in range(4):
+        R.ThreadWorker_Render(s, fb, 0, W * H - 1, 8, None, p, 4, 5)
+    R.ThreadWorker_Render(s, fb, 10, 9, 8, None, 0, 4, 5)        # begin > end: nothing, like the reference loop
+    accum, argb = fb.read_float(), fb.resolve_argb()
+    assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
+    with pytest.raises(R.RtwError):
+        R.ThreadWorker_Render(s, fb, 0, W * H, 8, None, 0, 4, 5)
+    with pytest.raises(R.RtwError):
+        R.ThreadWorker_Render(s, fb, 0, 10, 17, None, 0, 4, 5)
+
+
+def test_unitychan_textured_frame_vs_oracle(ctx, oracle_mod):
+    """Config 4 shape at reduced size: textured shading with alpha pass-through, bit-exact."""
+    O = oracle_mod
+    W, H = 320, 180
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("unitychan.obj"))
+    os_.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+    ofb = O.Framebuffer(W, H)
+    O.stats_reset()
+    os_.render_pass_pool(ofb, 4, False, 0, 4, 2024, threads=0, task_rows=10)
+    ostats = O.stats_get()
+    oa, ob = ofb.read()
+    assert ostats["tex_samples"] > 100
+    s = gpu_scene(ctx, "unitychan", R.SurfaceMaterial_Diffuse())
+    accum, argb = render_frame(ctx, s, W, H, 4, 4, 0, 2024)
+    assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
+
+
+def test_two_meshes_in_one_scene(ctx, oracle_mod):
+    """FindIntersectionWithScene over shapes in insertion order (closest wins, later shape on ties)."""
+    O = oracle_mod
+    os_ = O.Scene()
+    a = os_.add_mesh_obj(asset("TorusKnot.obj"))
+    b = os_.add_mesh_obj(asset("BlenderMonkey.obj"))
+    os_.set_material(a, [(O.MAT_DIFFUSE, (1, 0.5, 0.5), 0, 0, 0)])
+    os_.set_material(b, [(O.MAT_REFLECTIVE, (0.5, 1, 0.5), 0, 0, 0)])
+    ofb = O.Framebuffer(128, 128)
+    os_.render_range(ofb, 0, 128 * 128 - 1, 5, False, 0, 4, 31)
+    oa, ob = ofb.read()
+    s = R.RayTracerScene(ctx)
+    s.AddShape(R.RMeshShape.Create(asset("TorusKnot.obj")), R.SurfaceMaterial_Diffuse((1, 0.5, 0.5)))
+    s.AddShape(R.RMeshShape.Create(asset("BlenderMonkey.obj")), R.SurfaceMaterial_Reflective((0.5, 1, 0.5)))
+    accum, argb = render_frame(ctx, s, 128, 128, 4, 5, 0, 31)
+    assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
