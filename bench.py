@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--prune", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -164,6 +165,7 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     ctx = R.Context(local_rank, stream=stream.cuda_stream)
+    ctx.set_option("pipeline", args.pipeline)
     scene = R.RayTracerScene(ctx)
     scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
     scene.set_prune(args.prune)
@@ -281,7 +283,7 @@ def main():
             "config": {"workload": "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s])"
                                    % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3}[args.config]),
                        "sharding": "10-row tasks round-robin over ranks, one RCCL gather of the rows after the K passes",
-                       "seed": SEED, "prune": args.prune},
+                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline},
             "camera_Mrays_per_s": st["camera_rays"] / elapsed / 1e6,
             "rays_per_frame": rays_total / K,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

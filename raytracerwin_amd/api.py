@@ -225,6 +225,9 @@ class Context:
     def synchronize(self):
         _check(library().rtw_context_synchronize(self.h))
 
+    def set_option(self, name, value):
+        _check(library().rtw_context_set_option(self.h, name.encode(), int(value)))
+
     def stats_enable(self, on=True):
         _check(library().rtw_stats_enable(self.h, int(on)))
 

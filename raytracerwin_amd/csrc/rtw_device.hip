@@ -543,15 +543,42 @@ __device__ __forceinline__ uint32_t pack_pixel(const float* __restrict__ thr, f3
     return (255u << 24) | (gamma_channel(thr, c.x) << 16) | (gamma_channel(thr, c.y) << 8) | gamma_channel(thr, c.z);
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#ifndef RTW_HOST_EMUL
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#endif
+    return v;
+}
+// counters: one atomic per wave and counter (the whole wave must call this together)
 __device__ __forceinline__ void flush_counters(const RtwSceneDev* __restrict__ sc, const Counters& ct)
 {
+    const uint32_t r = wave_sum(ct.rays), b = wave_sum(ct.boxes), t = wave_sum(ct.tris), h = wave_sum(ct.hits), x = wave_sum(ct.tex), c = wave_sum(ct.cams);
+#ifndef RTW_HOST_EMUL
+    if ((threadIdx.x & 63) != 0) return;
+#endif
     if (!sc->stats) return;
-    atomicAdd(&sc->stats[0], (unsigned long long)ct.rays);
-    atomicAdd(&sc->stats[1], (unsigned long long)ct.boxes);
-    atomicAdd(&sc->stats[2], (unsigned long long)ct.tris);
-    atomicAdd(&sc->stats[3], (unsigned long long)ct.hits);
-    atomicAdd(&sc->stats[4], (unsigned long long)ct.tex);
-    atomicAdd(&sc->stats[5], (unsigned long long)ct.cams);
+    atomicAdd(&sc->stats[0], (unsigned long long)r);
+    atomicAdd(&sc->stats[1], (unsigned long long)b);
+    atomicAdd(&sc->stats[2], (unsigned long long)t);
+    atomicAdd(&sc->stats[3], (unsigned long long)h);
+    atomicAdd(&sc->stats[4], (unsigned long long)x);
+    atomicAdd(&sc->stats[5], (unsigned long long)c);
+}
+
+// AccumulatePixel::AddPixel + GetGammaSpacePixel, or the preview write (Src/RayTracerProgram.cpp:174-186)
+__device__ __forceinline__ void resolve_pixel(const float* __restrict__ thr, float4* __restrict__ accum, uint32_t* __restrict__ argb,
+                                              int pixel, f3 c, bool preview)
+{
+    if (preview) {
+        argb[pixel] = pack_pixel(thr, c);
+    } else {
+        const float4 a = accum[pixel];
+        const f3 sum = mk(a.x, a.y, a.z) + c;
+        const int n = __float_as_int(a.w) + 1;
+        accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+        argb[pixel] = pack_pixel(thr, sum / (float)n);
+    }
 }
 
 __device__ __forceinline__ int work_to_pixel(const RtwRenderParams& p, int wi)
@@ -571,32 +598,155 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
     thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
     __syncthreads();
     const int wi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= p.count) return;
-    const int pixel = work_to_pixel(p, wi);
     const int npix = p.width * p.height;
-    if (pixel >= npix) return;
+    const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    const uint32_t phase = table_phase(p.seed);
-    LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi;
-    if (!RTW_IN_RANGE(sc, 6, pixel, npix)) return;
-    f3 c = mk(0, 0, 0);
-    for (int i = 0; i < p.sub_samples; i++) {
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
-        const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
-        if (STATS) ct.cams++;
-        c = c + trace_path<STATS>(sc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
-    }
-    c = c / (float)p.sub_samples;
-    if (p.preview) {
-        argb[pixel] = pack_pixel(thr, c);
-    } else {
-        float4 a = accum[pixel];
-        const f3 sum = mk(a.x, a.y, a.z) + c;
-        const int n = __float_as_int(a.w) + 1;
-        accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
-        argb[pixel] = pack_pixel(thr, sum / (float)n);
+    if (pixel < npix) {
+        const uint32_t phase = table_phase(p.seed);
+        LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi;
+        f3 c = mk(0, 0, 0);
+        for (int i = 0; i < p.sub_samples; i++) {
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
+            const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
+            if (STATS) ct.cams++;
+            c = c + trace_path<STATS>(sc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+        }
+        c = c / (float)p.sub_samples;
+        resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
     }
     if (STATS) flush_counters(sc, ct);
+}
+
+// ======================================================================================================
+// Compacted pipeline (the default): the frame is rendered by three launches on the same stream.
+//   primary_kernel  one thread per pixel: camera rays + shape-bound tests.  Pixels whose samples all miss
+//                   every shape bound (92-97 % of a frame of the config scenes) are finished here, in one
+//                   streaming pass over the accumulator; the rest append one entry per live sample to a
+//                   path queue with one wave-aggregated atomic (ballot + popcount).
+//   path_kernel     one lane per queued path (grid-stride over the queue): the full bounce loop.
+//   resolve_kernel  one thread per pending pixel: sums its samples in sub-sample order and resolves.
+// Every float operation happens in the same order as in the one-kernel form, so both give the same bits.
+// ======================================================================================================
+struct PipeBufs {
+    uint32_t* __restrict__ queue;      // path id = work_item * 4 + sub_sample
+    uint32_t* __restrict__ pend;       // work items with at least one queued sample
+    float4* __restrict__ rad;          // radiance per path id (only slots of pending pixels are used)
+    uint32_t* __restrict__ counters;   // [0] queue length, [1] pending length
+    float4* __restrict__ ws;           // level store of path_kernel's threads
+};
+
+__device__ __forceinline__ void wave_push(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
+{
+#ifdef RTW_HOST_EMUL
+    if (flag) list[(*counter)++] = value;
+#else
+    const unsigned long long m = __ballot(flag);
+    if (m == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (flag) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+#endif
+}
+
+__device__ __forceinline__ f3 sky_color(float dir_y)        // Src/RayTracerScene.cpp:92-93
+{
+    const float t = 0.5f * (dir_y + 1.0f);
+    return mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
+                                                      uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
+    __syncthreads();
+    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = p.width * p.height;
+    const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
+    const bool live = pixel < npix;
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    f3 s[4];
+    uint32_t queued = 0;
+    if (live) {
+        const uint32_t phase = table_phase(p.seed);
+        const int n_shapes = sc->n_shapes;
+        for (int i = 0; i < 4; i++) {
+            s[i] = mk(0, 0, 0);
+            if (i >= p.sub_samples) continue;
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
+            const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
+            if (STATS) ct.cams++;
+            if (p.max_bounce == 0) continue;                 // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+            bool any = false;
+            for (int k = 0; k < n_shapes; k++) {
+                float t0, t1;
+                any = any || slab_exact(ray, sc->shapes[k].bmin[0], sc->shapes[k].bmin[1], sc->shapes[k].bmin[2],
+                                        sc->shapes[k].bmax[0], sc->shapes[k].bmax[1], sc->shapes[k].bmax[2], t0, t1);
+            }
+            if (any) queued |= 1u << i;
+            else { s[i] = sky_color(ray.d.y); if (STATS) { ct.rays++; ct.boxes += (uint32_t)n_shapes; } }
+        }
+        if (queued == 0) {
+            f3 c = mk(0, 0, 0);
+            for (int i = 0; i < 4; i++) if (i < p.sub_samples) c = c + s[i];
+            c = c / (float)p.sub_samples;
+            resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
+        } else {
+            for (int i = 0; i < 4; i++)
+                if (i < p.sub_samples && !(queued & (1u << i))) pb.rad[(size_t)wi * 4 + i] = make_float4(s[i].x, s[i].y, s[i].z, 0.0f);
+        }
+    }
+    for (int i = 0; i < 4; i++) wave_push(pb.queue, &pb.counters[0], (queued >> i) & 1u, (uint32_t)wi * 4u + (uint32_t)i);
+    wave_push(pb.pend, &pb.counters[1], queued != 0, (uint32_t)wi);
+    if (STATS) flush_counters(sc, ct);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p)
+{
+    const uint32_t n = pb.counters[0];
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = p.width * p.height;
+    const uint32_t phase = table_phase(p.seed);
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nthreads; lv.tid = (size_t)gtid;
+    for (uint32_t q = gtid; q < n; q += nthreads) {
+        const uint32_t pid = pb.queue[q];
+        const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
+        const int pixel = work_to_pixel(p, wi);
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
+        const Ray ray = camera_ray(p.width, p.height, pixel, sub, rng);
+        const f3 L = trace_path<STATS>(sc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+        pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
+                                                      uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
+    __syncthreads();
+    const uint32_t n = pb.counters[1];
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += nthreads) {
+        const uint32_t wi = pb.pend[k];
+        const int pixel = work_to_pixel(p, (int)wi);
+        f3 c = mk(0, 0, 0);
+        for (int i = 0; i < 4; i++) {
+            if (i >= p.sub_samples) break;
+            const float4 r = pb.rad[(size_t)wi * 4 + i];
+            c = c + mk(r.x, r.y, r.z);
+        }
+        c = c / (float)p.sub_samples;
+        resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
+    }
 }
 
 template <bool STATS>
@@ -657,6 +807,49 @@ int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, cons
     const int grid = (p.count + block - 1) / block;
     if (stats) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, (float4*)ws, p);
     else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, (float4*)ws, p);
+    return (int)hipGetLastError();
+}
+
+size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out)
+{
+    // queue | pend | counters | rad | level store
+    const size_t n = (size_t)(work_items > 0 ? work_items : 1);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    PipelineLayout l;
+    l.path_blocks = (int)((n * 4 + 255) / 256);
+    if (l.path_blocks > 2048) l.path_blocks = 2048;
+    l.queue_off = 0;
+    l.pend_off = l.queue_off + up(n * 4 * 4);
+    l.counters_off = l.pend_off + up(n * 4);
+    l.rad_off = l.counters_off + 256;
+    l.ws_off = l.rad_off + up(n * 4 * 16);
+    l.total = l.ws_off + (size_t)l.path_blocks * 256 * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
+    if (out) *out = l;
+    return l.total;
+}
+
+int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, bool stats, hipStream_t stream)
+{
+    if (p.count <= 0) return 0;
+    PipelineLayout l;
+    pipeline_workspace_bytes(p.count, p.max_bounce, &l);
+    char* w = (char*)workspace;
+    PipeBufs pb;
+    pb.queue = (uint32_t*)(w + l.queue_off); pb.pend = (uint32_t*)(w + l.pend_off); pb.counters = (uint32_t*)(w + l.counters_off);
+    pb.rad = (float4*)(w + l.rad_off); pb.ws = (float4*)(w + l.ws_off);
+    hipError_t e = hipMemsetAsync(pb.counters, 0, 16, stream);
+    if (e != hipSuccess) return (int)e;
+    const int block = 256;
+    const int grid = (p.count + block - 1) / block;
+    int resolve_blocks = grid < 1024 ? grid : 1024;
+    if (stats) {
+        hipLaunchKernelGGL(primary_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        hipLaunchKernelGGL(path_kernel<true>, dim3(l.path_blocks), dim3(block), 0, stream, sc, pb, p);
+    } else {
+        hipLaunchKernelGGL(primary_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        hipLaunchKernelGGL(path_kernel<false>, dim3(l.path_blocks), dim3(block), 0, stream, sc, pb, p);
+    }
+    hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     return (int)hipGetLastError();
 }
 

@@ -58,8 +58,9 @@ struct rtw_context {
     float* d_lut = nullptr;
     unsigned long long* d_stats = nullptr;
     bool stats_enabled = false;
-    void* d_workspace = nullptr;        // per-launch level store of the bounce recursion (grown on demand)
+    void* d_workspace = nullptr;        // per-launch queues / level store of the bounce recursion (grown on demand)
     size_t workspace_bytes = 0;
+    int pipeline = 1;                   // 1 = compacted three-launch pipeline (default), 0 = one kernel, one thread per pixel
 };
 
 struct rtw_scene {
@@ -157,6 +158,17 @@ int rtw_context_set_stream(rtw_context* ctx, void* hip_stream)
     if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     ctx->stream = (hipStream_t)hip_stream;
     return RTW_OK;
+}
+
+int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return fail(RTW_ERR_INVALID, "null argument");
+    if (std::strcmp(name, "pipeline") == 0) {
+        if (value != 0 && value != 1) return fail(RTW_ERR_INVALID, "pipeline must be 0 or 1");
+        ctx->pipeline = value;
+        return RTW_OK;
+    }
+    return fail(RTW_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 int rtw_context_synchronize(rtw_context* ctx)
@@ -544,8 +556,14 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     if (pass_index < 0) return fail(RTW_ERR_INVALID, "pass_index must be >= 0");
     p.width = fb->width; p.height = fb->height;
     p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
-    int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
-    hipError_t e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
+    hipError_t e;
+    if (scene->ctx->pipeline == 1) {
+        int rc = ensure_workspace(scene->ctx, rtw::pipeline_workspace_bytes(p.count, max_bounce, nullptr)); if (rc != RTW_OK) return rc;
+        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
+    } else {
+        int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
+        e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
+    }
     if (e != hipSuccess) return hip_fail(e, "render_kernel launch");
     return RTW_OK;
 }

@@ -292,3 +292,23 @@ def test_two_meshes_in_one_scene(ctx, oracle_mod):
     s.AddShape(R.RMeshShape.Create(asset("BlenderMonkey.obj")), R.SurfaceMaterial_Reflective((0.5, 1, 0.5)))
     accum, argb = render_frame(ctx, s, 128, 128, 4, 5, 0, 31)
     assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
+
+
+@pytest.mark.parametrize("mesh,ns,depth,preview", [("TorusKnot", 1, 4, 0), ("unitychan", 4, 4, 0), ("BlenderMonkey", 3, 0, 0),
+                                                   ("TorusKnot", 4, 3, 1)])
+def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
+    """The default three-launch pipeline (primary / path queue / resolve) and the one-thread-per-pixel
+    kernel give the same bits and the same work counters; 1280x720, two accumulated passes."""
+    W, H = 1280, 720
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
+    out = []
+    for mode in (0, 1):
+        ctx.set_option("pipeline", mode)
+        ctx.stats_enable(True)
+        ctx.stats_reset()
+        a, b = render_frame(ctx, s, W, H, ns, depth, preview, 4321, 0, 2)
+        out.append((a, b, ctx.stats()))
+        ctx.stats_enable(False)
+    ctx.set_option("pipeline", 1)
+    assert (bits(out[0][0]) == bits(out[1][0])).all() and (out[0][1] == out[1][1]).all()
+    assert out[0][2] == out[1][2]
