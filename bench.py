@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--prune", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=1)
+    ap.add_argument("--traversal", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -169,6 +170,7 @@ def main():
     scene = R.RayTracerScene(ctx)
     scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
     scene.set_prune(args.prune)
+    scene.set_traversal(args.traversal)
     scene.commit()
 
     with torch.cuda.stream(stream):
@@ -252,11 +254,13 @@ def main():
             verified = bool((a2.view(np.uint32).ravel() == final_accum).all() and (fb2.resolve_argb().view(np.int32) == final_argb).all())
         # reference-faithful visit counts (un-pruned order) of ONE pass for the algorithmic byte count
         scene.set_prune(0)
+        scene.set_traversal(0)
         ctx.stats_reset()
         fb2.clear()
         R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, 0, spp, SEED)
         st_ref = ctx.stats()
         scene.set_prune(args.prune)
+        scene.set_traversal(args.traversal)
         ctx.stats_reset()
         R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, 0, spp, SEED)
         st_run = ctx.stats()
@@ -283,7 +287,7 @@ def main():
             "config": {"workload": "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s])"
                                    % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3}[args.config]),
                        "sharding": "10-row tasks round-robin over ranks, one RCCL gather of the rows after the K passes",
-                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline},
+                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "traversal": args.traversal},
             "camera_Mrays_per_s": st["camera_rays"] / elapsed / 1e6,
             "rays_per_frame": rays_total / K,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -117,6 +117,12 @@ int rtw_scene_mesh_info(const rtw_scene* scene, int shape, int32_t info[8], floa
 int rtw_scene_mesh_nodes(const rtw_scene* scene, int shape, float* bounds6, int32_t* skip, int32_t* tri, int max_nodes);
 /* traversal pruning (result-preserving segment clip); default on */
 int rtw_scene_set_prune(rtw_scene* scene, int enabled);
+/* 1 (default): 4-wide collapsed tree, candidate leaves gathered in the reference's order before their
+ * triangle tests; 0: binary preorder walk that visits exactly the boxes KdNode::TestRayIntersection
+ * visits (Src/KdTree.cpp:128-195; used for reference-faithful work counters).  Same results. */
+int rtw_scene_set_traversal(rtw_scene* scene, int mode);
+/* 4-wide tree for inspection: returns the quad count; child4 as in rtw_types.h (leaf = -1 - original triangle) */
+int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int32_t* child4, int max_quads);
 
 /* ---- ray-level queries (parity surface) ---- */
 /* RayTracerScene::FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) for n rays.

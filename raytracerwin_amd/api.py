@@ -336,6 +336,9 @@ class RayTracerScene:
     def set_prune(self, enabled):
         _check(library().rtw_scene_set_prune(self.h, int(enabled)))
 
+    def set_traversal(self, mode):
+        _check(library().rtw_scene_set_traversal(self.h, int(mode)))
+
     def commit(self):
         if not self.committed:
             _check(library().rtw_scene_commit(self.h))
@@ -358,6 +361,15 @@ class RayTracerScene:
         t = np.zeros(n, np.int32)
         _check(library().rtw_scene_mesh_nodes(self.h, shape, _p(b), _p(s), _p(t), n))
         return b, s, t
+
+    def mesh_quads(self, shape=0):
+        self.commit()
+        n = library().rtw_scene_mesh_quads(self.h, shape, None, None, 0)
+        _check(n)
+        b = np.zeros((n, 6, 4), np.float32)
+        c = np.zeros((n, 4), np.int32)
+        _check(library().rtw_scene_mesh_quads(self.h, shape, _p(b), _p(c), n))
+        return b, c
 
     def FindIntersectionWithScene(self, rays):
         """rays: (n,7) origin, direction, distance -> (hits (n,11), shape (n,), triangle (n,))"""

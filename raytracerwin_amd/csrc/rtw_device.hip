@@ -85,6 +85,28 @@ __device__ __forceinline__ void rng_init(PathRng& r, uint32_t seed, uint32_t pha
 
 struct Counters { uint32_t rays, boxes, tris, hits, tex, cams; };
 
+// Loads/stores with an explicit address space.  Pointers that come out of the scene descriptor or out of a
+// struct are "generic" to the compiler, which then emits flat_* instructions (slower, and they tie the LDS
+// and vector-memory counters together); these helpers give it global_load_dwordx4 / ds_read_* instead.
+#if !defined(RTW_HOST_EMUL) && defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) const float4 rtw_g_f4;
+typedef __attribute__((address_space(1))) const float rtw_g_f1;
+typedef __attribute__((address_space(3))) const float rtw_l_f1;
+typedef __attribute__((address_space(3))) const uint32_t rtw_l_u1;
+typedef __attribute__((address_space(3))) uint32_t rtw_l_u1w;
+__device__ __forceinline__ float4 gld4(const float4* p, size_t i) { return ((rtw_g_f4*)p)[i]; }
+__device__ __forceinline__ float gld1(const float* p, size_t i) { return ((rtw_g_f1*)p)[i]; }
+__device__ __forceinline__ float lld1(const float* p, int i) { return ((rtw_l_f1*)p)[i]; }
+__device__ __forceinline__ uint32_t lldu(const uint32_t* p, int i) { return ((rtw_l_u1*)p)[i]; }
+__device__ __forceinline__ void lstu(uint32_t* p, int i, uint32_t v) { ((rtw_l_u1w*)p)[i] = v; }
+#else
+__device__ __forceinline__ float4 gld4(const float4* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float gld1(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float lld1(const float* p, int i) { return p[i]; }
+__device__ __forceinline__ uint32_t lldu(const uint32_t* p, int i) { return p[i]; }
+__device__ __forceinline__ void lstu(uint32_t* p, int i, uint32_t v) { p[i] = v; }
+#endif
+
 // RTW_BOUNDS_DEBUG build: every indexed global access is range-checked first; a violation is recorded in
 // stats[6] (site code) / stats[7] (offending value) and the access is skipped instead of faulting.
 #ifdef RTW_BOUNDS_DEBUG
@@ -183,7 +205,7 @@ __device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, co
     const float4* tr4 = reinterpret_cast<const float4*>(tris);
     while (i < n_nodes) {
         if (!RTW_IN_RANGE(sc, 1, i, n_nodes)) break;
-        const float4 lo = nd4[2 * i], hi = nd4[2 * i + 1];
+        const float4 lo = gld4(nd4, 2 * (size_t)i), hi = gld4(nd4, 2 * (size_t)i + 1);
         const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
         bool hit; float tmin, tmax;
         if (TAME) {
@@ -199,7 +221,7 @@ __device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, co
         }
         if (STATS) ct.boxes++;
         if (hit && leaf >= 0 && RTW_IN_RANGE(sc, 2, leaf, n_tris)) {
-            const float4 a = tr4[4 * leaf], b = tr4[4 * leaf + 1], c = tr4[4 * leaf + 2], d = tr4[4 * leaf + 3];
+            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
             if (STATS) ct.tris++;
             f3 cp; float dist;
             if (triangle_test(r, cur_dist, a, b, c, d.x, cp, dist)) {
@@ -210,6 +232,254 @@ __device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, co
     }
     return any;
 }
+
+// ---- 4-wide walk -------------------------------------------------------------------------------------
+// Per-lane working memory in LDS: a trail of (quad, remaining-slot mask) per tree level and the list of
+// candidate leaves gathered so far, both indexed [entry * block_threads + thread] (conflict-free).
+// `tid`/`nthr` index the owner of a list: a lane (one lane per ray) or a quartet (four lanes per ray).
+struct TravCtx {
+    uint32_t* trail;            // RTW_QUAD_STACK entries per owner
+    uint32_t* cand;             // RTW_CAND_CAP entries per owner
+    const float* lds_quads;     // all quads of shape 0, staged in LDS by the block (quartet kernels only; may be null)
+    int tid, nthr;
+    int lane4;                  // lane & 3 (quartet kernels)
+    bool count;                 // this lane adds the per-ray counters (lane 0 of a quartet, or every lane)
+};
+#define RTW_TRAV_LDS_WORDS ((RTW_QUAD_STACK + RTW_CAND_CAP) * 256)
+
+__device__ __forceinline__ TravCtx make_trav(uint32_t* lds_words)
+{
+    TravCtx t;
+    t.trail = lds_words; t.cand = lds_words + RTW_QUAD_STACK * 256;
+    t.lds_quads = nullptr;
+    t.tid = (int)threadIdx.x; t.nthr = 256; t.lane4 = 0; t.count = true;
+    return t;
+}
+// four lanes per ray: owner = quartet
+__device__ __forceinline__ TravCtx make_trav4(uint32_t* lds_words, int block_threads, const float* lds_quads)
+{
+    TravCtx t;
+    const int quartets = block_threads / 4;
+    t.trail = lds_words; t.cand = lds_words + RTW_QUAD_STACK * quartets;
+    t.lds_quads = lds_quads;
+    t.tid = (int)(threadIdx.x >> 2); t.nthr = quartets; t.lane4 = (int)(threadIdx.x & 3u); t.count = (threadIdx.x & 3u) == 0u;
+    return t;
+}
+
+// Same result as tree_walk<true>: the leaves whose own box the ray's line hits are met in the binary tree's
+// preorder (slots are ordered, children are walked depth-first), gathered RTW_CAND_CAP at a time, and then
+// triangle-tested in that order with the shrinking segment, exactly as KdNode::TestRayIntersection does.
+// Box tests of a gathering phase use the segment length known when the phase started (still conservative).
+template <bool STATS>
+__device__ __forceinline__ bool quad_walk(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
+                                          float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
+{
+    const float ix = 1.0f / r.d.x, iy = 1.0f / r.d.y, iz = 1.0f / r.d.z;
+    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+    const float4* gq = reinterpret_cast<const float4*>(sh.quads);
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    bool any = false;
+    int sp = 0;                 // trail depth
+    uint32_t m = 0;             // remaining hit slots of the current quad (bit k = slot k)
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int q = 0;
+    bool need_node = true;      // the next step loads quad q and tests its four boxes
+    bool walking = true;
+    while (walking) {
+        int ncand = 0;
+        // ---- gather: walk until the candidate list is full or the tree is exhausted ----
+        for (;;) {
+            if (need_node) {
+                const size_t qb = (size_t)q * 8;
+                const float4 mnx = gld4(gq, qb), mny = gld4(gq, qb + 1), mnz = gld4(gq, qb + 2);
+                const float4 mxx = gld4(gq, qb + 3), mxy = gld4(gq, qb + 4), mxz = gld4(gq, qb + 5), chf = gld4(gq, qb + 6);
+                c0 = __float_as_int(chf.x); c1 = __float_as_int(chf.y); c2 = __float_as_int(chf.z); c3 = __float_as_int(chf.w);
+                const float far_t = cur_dist + (eps_t + 1.0e-4f * cur_dist);
+                m = 0;
+#define RTW_SLOT(K, MNX, MNY, MNZ, MXX, MXY, MXZ, CH)                                                        \
+                {                                                                                             \
+                    const float x1 = (MNX - r.o.x) * ix, x2 = (MXX - r.o.x) * ix;                             \
+                    const float y1 = (MNY - r.o.y) * iy, y2 = (MXY - r.o.y) * iy;                             \
+                    const float z1 = (MNZ - r.o.z) * iz, z2 = (MXZ - r.o.z) * iz;                             \
+                    const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));             \
+                    const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));             \
+                    bool h = (tmax > tmin) && (CH != RTW_QUAD_EMPTY);                                          \
+                    if (prune) h = h && !(tmin > far_t) && !(tmax < -eps_t);                                  \
+                    if (h) m |= 1u << K;                                                                      \
+                }
+                RTW_SLOT(0, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, c0)
+                RTW_SLOT(1, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, c1)
+                RTW_SLOT(2, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, c2)
+                RTW_SLOT(3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, c3)
+#undef RTW_SLOT
+                if (STATS) ct.boxes += (c0 != RTW_QUAD_EMPTY) + (c1 != RTW_QUAD_EMPTY) + (c2 != RTW_QUAD_EMPTY) + (c3 != RTW_QUAD_EMPTY);
+                need_node = false;
+            }
+            // consume slots in order: leaves join the list, the first internal slot is descended into
+            int next = -1;
+            bool full = false;
+            for (;;) {
+                if (m == 0u) {
+                    if (sp == 0) break;
+                    sp--;
+                    const uint32_t e = lldu(tc.trail, sp * tc.nthr + tc.tid);
+                    q = (int)(e >> 4); m = e & 15u;
+                    const float4 chf = gld4(gq, (size_t)q * 8 + 6);
+                    c0 = __float_as_int(chf.x); c1 = __float_as_int(chf.y); c2 = __float_as_int(chf.z); c3 = __float_as_int(chf.w);
+                    continue;
+                }
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1u;
+                const int ch = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+                if (ch < 0) {
+                    lstu(tc.cand, ncand * tc.nthr + tc.tid, (uint32_t)(-1 - ch));
+                    ncand++;
+                    if (ncand == RTW_CAND_CAP) { full = true; break; }
+                    continue;
+                }
+                next = ch;
+                break;
+            }
+            if (next >= 0) {
+                if (m != 0u) { lstu(tc.trail, sp * tc.nthr + tc.tid, ((uint32_t)q << 4) | m); sp++; }
+                q = next; need_node = true;
+                continue;
+            }
+            if (!full) walking = false;      // trail empty and no slot left: the tree is exhausted
+            break;
+        }
+        // ---- triangle tests of the gathered leaves, in order ----
+        for (int j = 0; j < ncand; j++) {
+            const int leaf = (int)tc.cand[j * tc.nthr + tc.tid];
+            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
+            if (STATS) ct.tris++;
+            f3 cp; float dist;
+            if (triangle_test(r, cur_dist, a, b, c, d.x, cp, dist)) { cur_dist = dist; hit_pos = cp; hit_slot = leaf; any = true; }
+        }
+    }
+    return any;
+}
+
+// ---- 4-wide walk, four lanes per ray -----------------------------------------------------------------
+// The four lanes of a quartet hold the same ray and the same control state; lane k owns slot k of the
+// current quad (one box test per lane instead of four), the hit mask is the quartet's nibble of the wave
+// ballot, and candidate leaves are triangle-tested four at a time.  A triangle test must see the segment
+// length left by every earlier accepted hit (the reference tests them one after another), so after an
+// accept the later lanes of the group are tested again with the shortened segment.
+#ifndef RTW_HOST_EMUL
+__device__ __forceinline__ int quad_bcast(int v, int k)      // value of lane k of this lane's quartet
+{
+    const int b0 = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
+    const int b1 = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
+    const int b2 = __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true);
+    const int b3 = __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true);
+    return k == 0 ? b0 : (k == 1 ? b1 : (k == 2 ? b2 : b3));
+}
+__device__ __forceinline__ float quad_bcastf(float v, int k) { return __int_as_float(quad_bcast(__float_as_int(v), k)); }
+
+template <bool STATS, bool LDSQ>
+__device__ __forceinline__ bool quad_walk4(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
+                                           float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
+{
+    const float ix = 1.0f / r.d.x, iy = 1.0f / r.d.y, iz = 1.0f / r.d.z;
+    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+    const float* gqf = reinterpret_cast<const float*>(sh.quads);
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    const int k4 = tc.lane4;
+    const int nibble_shift = (int)(threadIdx.x & 60u);       // first lane of this quartet within the wave
+    bool any = false;
+    int sp = 0;
+    uint32_t m = 0;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int q = 0;
+    bool need_node = true;
+    bool walking = true;
+    while (walking) {
+        int ncand = 0;
+        for (;;) {
+            if (need_node) {
+                float mnx, mny, mnz, mxx, mxy, mxz; int ch;
+                const int qb = q * 32 + k4;
+                if (LDSQ) {
+                    mnx = lld1(tc.lds_quads, qb); mny = lld1(tc.lds_quads, qb + 4); mnz = lld1(tc.lds_quads, qb + 8);
+                    mxx = lld1(tc.lds_quads, qb + 12); mxy = lld1(tc.lds_quads, qb + 16); mxz = lld1(tc.lds_quads, qb + 20);
+                    ch = __float_as_int(lld1(tc.lds_quads, qb + 24));
+                } else {
+                    mnx = gld1(gqf, (size_t)qb); mny = gld1(gqf, (size_t)qb + 4); mnz = gld1(gqf, (size_t)qb + 8);
+                    mxx = gld1(gqf, (size_t)qb + 12); mxy = gld1(gqf, (size_t)qb + 16); mxz = gld1(gqf, (size_t)qb + 20);
+                    ch = __float_as_int(gld1(gqf, (size_t)qb + 24));
+                }
+                const float x1 = (mnx - r.o.x) * ix, x2 = (mxx - r.o.x) * ix;
+                const float y1 = (mny - r.o.y) * iy, y2 = (mxy - r.o.y) * iy;
+                const float z1 = (mnz - r.o.z) * iz, z2 = (mxz - r.o.z) * iz;
+                const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                bool h = (tmax > tmin) && (ch != RTW_QUAD_EMPTY);
+                if (prune) h = h && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
+                if (STATS) ct.boxes += (ch != RTW_QUAD_EMPTY);
+                const unsigned long long bal = __ballot(h);
+                m = (uint32_t)(bal >> nibble_shift) & 15u;
+                c0 = __builtin_amdgcn_mov_dpp(ch, 0x00, 0xf, 0xf, true); c1 = __builtin_amdgcn_mov_dpp(ch, 0x55, 0xf, 0xf, true);
+                c2 = __builtin_amdgcn_mov_dpp(ch, 0xAA, 0xf, 0xf, true); c3 = __builtin_amdgcn_mov_dpp(ch, 0xFF, 0xf, 0xf, true);
+                need_node = false;
+            }
+            int next = -1;
+            bool full = false;
+            for (;;) {
+                if (m == 0u) {
+                    if (sp == 0) break;
+                    sp--;
+                    const uint32_t e = lldu(tc.trail, sp * tc.nthr + tc.tid);
+                    q = (int)(e >> 4); m = e & 15u;
+                    const int ch = LDSQ ? __float_as_int(lld1(tc.lds_quads, q * 32 + 24 + k4)) : __float_as_int(gld1(gqf, (size_t)q * 32 + 24 + k4));
+                    c0 = __builtin_amdgcn_mov_dpp(ch, 0x00, 0xf, 0xf, true); c1 = __builtin_amdgcn_mov_dpp(ch, 0x55, 0xf, 0xf, true);
+                    c2 = __builtin_amdgcn_mov_dpp(ch, 0xAA, 0xf, 0xf, true); c3 = __builtin_amdgcn_mov_dpp(ch, 0xFF, 0xf, 0xf, true);
+                    continue;
+                }
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1u;
+                const int ch = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+                if (ch < 0) {
+                    lstu(tc.cand, ncand * tc.nthr + tc.tid, (uint32_t)(-1 - ch));      // all four lanes store the same word
+                    ncand++;
+                    if (ncand == RTW_CAND_CAP) { full = true; break; }
+                    continue;
+                }
+                next = ch;
+                break;
+            }
+            if (next >= 0) {
+                if (m != 0u) { lstu(tc.trail, sp * tc.nthr + tc.tid, ((uint32_t)q << 4) | m); sp++; }
+                q = next; need_node = true;
+                continue;
+            }
+            if (!full) walking = false;
+            break;
+        }
+        // ---- triangle tests, four candidates at a time (lane k takes candidate j + k) ----
+        for (int j = 0; j < ncand; j += 4) {
+            const bool mine = j + k4 < ncand;
+            const int leaf = mine ? (int)lldu(tc.cand, (j + k4) * tc.nthr + tc.tid) : 0;
+            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
+            if (STATS) ct.tris += mine ? 1u : 0u;
+            int settled = -1;                    // lanes <= settled have their final verdict
+            for (;;) {
+                f3 cp = mk(0, 0, 0); float dist = 0.0f;
+                const bool acc = mine && k4 > settled && triangle_test(r, cur_dist, a, b, c, d.x, cp, dist);
+                const uint32_t am = (uint32_t)(__ballot(acc) >> nibble_shift) & 15u;
+                if (am == 0u) break;
+                const int first = __ffs((int)am) - 1;
+                cur_dist = quad_bcastf(dist, first);
+                hit_pos = mk(quad_bcastf(cp.x, first), quad_bcastf(cp.y, first), quad_bcastf(cp.z, first));
+                hit_slot = quad_bcast(leaf, first);
+                any = true;
+                settled = first;
+            }
+        }
+    }
+    return any;
+}
+#endif
 
 // ---- RTexture::Sample (Src/Texture.cpp:23-57) on RGBA8 texels + the host LUT ---------------------
 __device__ __forceinline__ void texel_fetch(const uint32_t* __restrict__ tex, const float* __restrict__ lut, int idx, float& r, float& g, float& b, float& a)
@@ -242,21 +512,40 @@ __device__ __forceinline__ void texture_sample(const uint32_t* __restrict__ texe
 }
 
 // ---- RMeshShape::TestRayIntersection (Src/MeshShape.cpp:280-332) ------------------------------------
-template <bool STATS>
-__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, const Ray& r, float seg_dist,
-                                           Hit& out, int& tri_index, Counters& ct)
+// LPR = lanes per ray (1, or 4 in the quartet path kernel); LDSQ = shape 0's quads are staged in LDS.
+// In a quartet the four lanes run everything but quad_walk4 redundantly on identical state; Counters
+// `walk` collects what is counted per lane (box / triangle tests), `ct` what is counted once per ray.
+template <bool STATS, int LPR, bool LDSQ>
+__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, bool first_shape, const TravCtx& tc,
+                                           const Ray& r, float seg_dist, Hit& out, int& tri_index, Counters& ct)
 {
     float cur = seg_dist; f3 pos = mk(0, 0, 0); int slot = -1;
     bool any;
-    if (ray_is_tame(r)) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, ct);
-    else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, ct);
+    Counters walk = { 0, 0, 0, 0, 0, 0 };
+    if (ray_is_tame(r)) {
+        if (sc->traversal != 0 && sh.n_quads > 0) {
+#ifndef RTW_HOST_EMUL
+            if (LPR == 4) {
+                if (LDSQ && first_shape) any = quad_walk4<STATS, true>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+                else any = quad_walk4<STATS, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
+            } else
+#endif
+                any = quad_walk<STATS>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+        } else {
+            any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, walk);
+        }
+    } else {
+        any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, walk);
+    }
+    if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
     if (!any) return false;
     if (!RTW_IN_RANGE(sc, 3, slot, sh.n_tris)) return false;
-    if (STATS) ct.hits++;
+    if (STATS && tc.count) ct.hits++;
     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
-    const float4 ta = tr4[4 * slot], tb = tr4[4 * slot + 1], tc = tr4[4 * slot + 2], td = tr4[4 * slot + 3];
+    const float4 ta = gld4(tr4, 4 * (size_t)slot), tb = gld4(tr4, 4 * (size_t)slot + 1), tcc = gld4(tr4, 4 * (size_t)slot + 2), td = gld4(tr4, 4 * (size_t)slot + 3);
     tri_index = __float_as_int(td.y);
-    const f3 a = mk(ta.x, ta.y, ta.z), b = mk(tb.x, tb.y, tb.z), c = mk(tc.x, tc.y, tc.z);
+    const f3 a = mk(ta.x, ta.y, ta.z), b = mk(tb.x, tb.y, tb.z), c = mk(tcc.x, tcc.y, tcc.z);
     // RMath::Barycentric (Src/Math.cpp:56-68)
     const f3 v0 = b - a, v1 = c - a, v2 = pos - a;
     const float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
@@ -265,7 +554,7 @@ __device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, c
     const float bw = (d00 * d21 - d01 * d20) / denom;
     const float bu = 1.0f - bv - bw;
     const float4* sh4 = reinterpret_cast<const float4*>(sh.shade);
-    const float4 s0 = sh4[4 * slot], s1 = sh4[4 * slot + 1], s2 = sh4[4 * slot + 2], s3 = sh4[4 * slot + 3];
+    const float4 s0 = gld4(sh4, 4 * (size_t)slot), s1 = gld4(sh4, 4 * (size_t)slot + 1), s2 = gld4(sh4, 4 * (size_t)slot + 2), s3 = gld4(sh4, 4 * (size_t)slot + 3);
     const f3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
     out.pos = pos;
     out.dist = cur;
@@ -276,25 +565,25 @@ __device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, c
     if (mat != -1 && mat < sh.n_textures && mat < RTW_DEV_MAX_TEXTURES && sh.textures[mat].valid) {
         const float tu = (s2.y * bu + s2.w * bv) + s3.y * bw;      // t0*u + t1*v + t2*w
         const float tv = (s2.z * bu + s3.x * bv) + s3.z * bw;
-        if (STATS) ct.tex++;
+        if (STATS && tc.count) ct.tex++;
         texture_sample(sh.texels, sh.textures[mat], sc->texel_lut, tu, 1.0f - tv, out.color, out.alpha);
     }
     return true;
 }
 
 // ---- RayTracerScene::FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) ------------------------
-template <bool STATS>
-__device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__ sc, const Ray& in, Hit& out, int& tri_index, Counters& ct)
+template <bool STATS, int LPR, bool LDSQ>
+__device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, const Ray& in, Hit& out, int& tri_index, Counters& ct)
 {
     int hit_shape = -1;
     float seg = in.dist;
-    if (STATS) ct.rays++;
+    if (STATS && tc.count) ct.rays++;
     for (int s = 0; s < sc->n_shapes; s++) {
         const RtwShapeDev& sh = sc->shapes[s];
         float t0, t1;
-        if (STATS) ct.boxes++;
+        if (STATS && tc.count) ct.boxes++;
         if (!slab_exact(in, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
-        if (mesh_query<STATS>(sc, sh, in, seg, out, tri_index, ct)) { seg = out.dist; hit_shape = s; }
+        if (mesh_query<STATS, LPR, LDSQ>(sc, sh, s == 0, tc, in, seg, out, tri_index, ct)) { seg = out.dist; hit_shape = s; }
     }
     return hit_shape;
 }
@@ -325,8 +614,8 @@ __device__ __forceinline__ f3 hemisphere_direction(const RtwSceneDev* __restrict
     const uint32_t idx = mod_table_size(rng.table_base + rng.table_reads);   // RMath::PseudoRandomUnitVector, per-path cursor
     rng.table_reads++;
     if (!RTW_IN_RANGE(sc, 4, idx, RTW_TABLE_SIZE)) return normal;
-    const float* e = sc->unit_table + (size_t)idx * 3;
-    const f3 v = mk(e[0], e[1], e[2]);
+    const float* e = sc->unit_table;
+    const f3 v = mk(gld1(e, (size_t)idx * 3), gld1(e, (size_t)idx * 3 + 1), gld1(e, (size_t)idx * 3 + 2));
     if (dot(v, normal) > 0.0f) return v;                                          // Src/Math.cpp:42-54
     return reflect(v, normal);
 }
@@ -449,8 +738,8 @@ struct LevelStore {
     __device__ __forceinline__ float4& at(int level, int j) const { return ws[((size_t)level * 3 + (size_t)j) * stride + tid]; }
 };
 
-template <bool STATS>
-__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv)
+template <bool STATS, int LPR, bool LDSQ>
+__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv)
 {
     int nlev = 0;
     f3 L = mk(0, 0, 0);
@@ -458,7 +747,7 @@ __device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, Ray ray, int max_bo
     for (;;) {
         if (depth == 0) { L = mk(0, 0, 0); break; }
         Hit h; int tri;
-        const int s = find_intersection<STATS>(sc, ray, h, tri, ct);
+        const int s = find_intersection<STATS, LPR, LDSQ>(sc, tc, ray, h, tri, ct);
         if (s < 0) {                                                     // sky (Src/RayTracerScene.cpp:89-94)
             const float t = 0.5f * (ray.d.y + 1.0f);
             L = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
@@ -595,8 +884,10 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
                                                      uint32_t* __restrict__ argb, float4* __restrict__ ws, RtwRenderParams p)
 {
     __shared__ float thr[256];
+    __shared__ uint32_t trav_words[RTW_TRAV_LDS_WORDS];
     thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
     __syncthreads();
+    const TravCtx tc = make_trav(trav_words);
     const int wi = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = p.width * p.height;
     const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
@@ -609,7 +900,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
             PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
             const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
             if (STATS) ct.cams++;
-            c = c + trace_path<STATS>(sc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+            c = c + trace_path<STATS, 1, false>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
         }
         c = c / (float)p.sub_samples;
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
@@ -705,26 +996,43 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
     if (STATS) flush_counters(sc, ct);
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(256) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p)
+// One quartet (4 lanes) per queued path; NT threads per block.  With LDSQ the block first stages every quad of
+// shape 0 (breadth-first array) in LDS; the per-quartet trail and candidate list live in LDS as well.
+template <bool STATS, bool LDSQ, int NT>
+__global__ __launch_bounds__(NT) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
 {
+#ifdef RTW_HOST_EMUL
+    (void)sc; (void)pb; (void)p; (void)lds_quad_count;
+#else
+    __shared__ uint32_t trav_words[(RTW_QUAD_STACK + RTW_CAND_CAP) * (NT / 4)];
+    extern __shared__ float lds_quads[];
+    // the grid is sized for the worst case (every sample queued); blocks past the real queue leave at once
+    if (blockIdx.x * (uint32_t)(NT / 4) >= pb.counters[0]) return;
+    if (LDSQ) {
+        const float4* src = reinterpret_cast<const float4*>(sc->shapes[0].quads);
+        float4* dst = reinterpret_cast<float4*>(lds_quads);
+        for (int i = (int)threadIdx.x; i < lds_quad_count * 8; i += NT) dst[i] = gld4(src, (size_t)i);
+        __syncthreads();
+    }
+    const TravCtx tc = make_trav4(trav_words, NT, LDSQ ? lds_quads : nullptr);
     const uint32_t n = pb.counters[0];
-    const uint32_t nthreads = gridDim.x * blockDim.x;
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nquartets = gridDim.x * (NT / 4);
+    const uint32_t gq = blockIdx.x * (NT / 4) + (threadIdx.x >> 2);
     const int npix = p.width * p.height;
     const uint32_t phase = table_phase(p.seed);
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nthreads; lv.tid = (size_t)gtid;
-    for (uint32_t q = gtid; q < n; q += nthreads) {
+    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nquartets; lv.tid = (size_t)gq;
+    for (uint32_t q = gq; q < n; q += nquartets) {
         const uint32_t pid = pb.queue[q];
         const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
         const int pixel = work_to_pixel(p, wi);
         PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
         const Ray ray = camera_ray(p.width, p.height, pixel, sub, rng);
-        const f3 L = trace_path<STATS>(sc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
-        pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+        const f3 L = trace_path<STATS, 4, LDSQ>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+        if (tc.lane4 == 0) pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
     }
     if (STATS) flush_counters(sc, ct);
+#endif
 }
 
 __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
@@ -753,13 +1061,15 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void closest_kernel(const RtwSceneDev* __restrict__ sc, const float* __restrict__ rays, long long n,
                                                       float* __restrict__ hits11, int* __restrict__ shape, int* __restrict__ tri)
 {
+    __shared__ uint32_t trav_words[RTW_TRAV_LDS_WORDS];
+    const TravCtx tc = make_trav(trav_words);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r; r.o = mk(rays[i * 7], rays[i * 7 + 1], rays[i * 7 + 2]); r.d = mk(rays[i * 7 + 3], rays[i * 7 + 4], rays[i * 7 + 5]); r.dist = rays[i * 7 + 6];
     Hit h; h.pos = mk(0, 0, 0); h.normal = mk(0, 0, 0); h.dist = 0.0f; h.color = mk(1, 1, 1); h.alpha = 1.0f;   // RayHitResult()
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     int t = -1;
-    const int s = find_intersection<STATS>(sc, r, h, t, ct);
+    const int s = find_intersection<STATS, 1, false>(sc, tc, r, h, t, ct);
     float* o = hits11 + i * 11;
     o[0] = h.pos.x; o[1] = h.pos.y; o[2] = h.pos.z; o[3] = h.normal.x; o[4] = h.normal.y; o[5] = h.normal.z; o[6] = h.dist;
     o[7] = h.color.x; o[8] = h.color.y; o[9] = h.color.z; o[10] = h.alpha;
@@ -772,6 +1082,8 @@ __global__ __launch_bounds__(256) void ray_trace_kernel(const RtwSceneDev* __res
                                                         const uint32_t* __restrict__ keys2, long long n, int max_bounce, int preview,
                                                         uint32_t seed, unsigned long long npix, float* __restrict__ rgb, float4* __restrict__ ws)
 {
+    __shared__ uint32_t trav_words[RTW_TRAV_LDS_WORDS];
+    const TravCtx tc = make_trav(trav_words);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r; r.o = mk(rays[i * 7], rays[i * 7 + 1], rays[i * 7 + 2]); r.d = mk(rays[i * 7 + 3], rays[i * 7 + 4], rays[i * 7 + 5]); r.dist = rays[i * 7 + 6];
@@ -779,7 +1091,7 @@ __global__ __launch_bounds__(256) void ray_trace_kernel(const RtwSceneDev* __res
     const uint32_t pixel = keys2[i * 2], sample = keys2[i * 2 + 1];
     PathRng rng; rng_init(rng, seed, table_phase(seed), npix, pixel, sample / 4u, sample % 4u);
     LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)i;
-    const f3 c = trace_path<STATS>(sc, r, max_bounce, preview != 0, rng, ct, lv);
+    const f3 c = trace_path<STATS, 1, false>(sc, tc, r, max_bounce, preview != 0, rng, ct, lv);
     rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
     if (STATS) flush_counters(sc, ct);
 }
@@ -816,19 +1128,18 @@ size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLa
     const size_t n = (size_t)(work_items > 0 ? work_items : 1);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     PipelineLayout l;
-    l.path_blocks = (int)((n * 4 + 255) / 256);
-    if (l.path_blocks > 2048) l.path_blocks = 2048;
+    l.path_quartets = n * 4 < (size_t)RTW_MAX_PATH_QUARTETS ? (int)(n * 4) : RTW_MAX_PATH_QUARTETS;   // one quartet per path, capped
     l.queue_off = 0;
     l.pend_off = l.queue_off + up(n * 4 * 4);
     l.counters_off = l.pend_off + up(n * 4);
     l.rad_off = l.counters_off + 256;
     l.ws_off = l.rad_off + up(n * 4 * 16);
-    l.total = l.ws_off + (size_t)l.path_blocks * 256 * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
+    l.total = l.ws_off + ((size_t)l.path_quartets + 256) * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
     if (out) *out = l;
     return l.total;
 }
 
-int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, bool stats, hipStream_t stream)
+int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, bool stats, hipStream_t stream)
 {
     if (p.count <= 0) return 0;
     PipelineLayout l;
@@ -842,12 +1153,20 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     const int block = 256;
     const int grid = (p.count + block - 1) / block;
     int resolve_blocks = grid < 1024 ? grid : 1024;
-    if (stats) {
-        hipLaunchKernelGGL(primary_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-        hipLaunchKernelGGL(path_kernel<true>, dim3(l.path_blocks), dim3(block), 0, stream, sc, pb, p);
+    if (stats) hipLaunchKernelGGL(primary_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    else hipLaunchKernelGGL(primary_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    if (lds_quad_count > 0) {
+        // small mesh: every quad of shape 0 in LDS, big blocks so that the staged tree is shared by 16 waves
+        constexpr int NT = RTW_PATH_BLOCK_LDS;
+        const int blocks = (l.path_quartets + NT / 4 - 1) / (NT / 4);
+        const size_t dyn = (size_t)lds_quad_count * 128;
+        if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
+        else hipLaunchKernelGGL((path_kernel<false, true, NT>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
     } else {
-        hipLaunchKernelGGL(primary_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-        hipLaunchKernelGGL(path_kernel<false>, dim3(l.path_blocks), dim3(block), 0, stream, sc, pb, p);
+        constexpr int NT = 256;
+        const int blocks = (l.path_quartets + NT / 4 - 1) / (NT / 4);
+        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        else hipLaunchKernelGGL((path_kernel<false, false, NT>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
     }
     hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     return (int)hipGetLastError();

@@ -31,6 +31,8 @@ struct HostMesh {
     std::vector<RtwNode> nodes;
     std::vector<RtwTri> tris;          // leaf order
     std::vector<RtwShade> shade;       // leaf order
+    std::vector<RtwQuad> quads;        // 4-wide collapse of `nodes`, BFS order
+    int quad_depth = 0;
     int max_depth = 0;
     int n_tris() const { return (int)(point_idx.size() / 3); }
 };
@@ -42,6 +44,8 @@ std::string load_obj(const std::string& path, HostMesh& out);
 std::string finish_arrays(HostMesh& m, const float* bounds6);
 // KdNode::Build restated (Src/KdTree.cpp:37-126) + flatten to preorder/skip-link form.
 void build_tree(HostMesh& m);
+// 4-wide collapse of m.nodes (slot order = preorder), numbered breadth-first.
+void build_quads(HostMesh& m);
 
 // tables
 uint32_t rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);

@@ -31,6 +31,20 @@ struct RtwShade {           // 4 x 16 B
 };
 static_assert(sizeof(RtwShade) == 64, "RtwShade");
 
+// 4-wide collapse of the same binary tree (slots keep the binary tree's left-to-right order, so a
+// depth-first walk meets the leaves in exactly the reference's order).  Slot boxes are the binary
+// nodes' own boxes; an empty slot has an inverted box that no ray can hit.
+struct RtwQuad {            // 8 x 16 B
+    float min_x[4], min_y[4], min_z[4];
+    float max_x[4], max_y[4], max_z[4];
+    int32_t child[4];       // >= 0: quad index; < 0 and != RTW_QUAD_EMPTY: leaf slot = -1 - child; RTW_QUAD_EMPTY: unused
+    int32_t pad[4];
+};
+static_assert(sizeof(RtwQuad) == 128, "RtwQuad");
+#define RTW_QUAD_EMPTY ((int32_t)0x80000000)
+#define RTW_QUAD_STACK 16   // deepest quad tree the LDS trail holds
+#define RTW_CAND_CAP 24     // candidate leaves gathered before their triangle tests run
+
 struct RtwTexture {         // 16 B
     uint32_t offset;        // first texel in the atlas
     int32_t width, height;
@@ -50,7 +64,9 @@ struct RtwShapeDev {
     const RtwTri* tris;
     const RtwShade* shade;
     const uint32_t* texels;
+    const RtwQuad* quads;           // BFS order; null / n_quads == 0 -> binary walk only
     float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
+    int32_t n_quads, quad_depth;
     int32_t n_nodes, n_tris;
     int32_t n_textures;             // size of the reference's Textures vector (= triangle count when an MTL exists)
     int32_t has_material;
@@ -63,6 +79,8 @@ struct RtwShapeDev {
 struct RtwSceneDev {
     int32_t n_shapes;
     int32_t prune;
+    int32_t traversal;              // 1: 4-wide walk (default), 0: binary preorder walk (reference visit counts)
+    int32_t pad0;
     const float* unit_table;        // 3 floats per entry
     const float* gamma_thr;         // 256
     const float* texel_lut;         // 256

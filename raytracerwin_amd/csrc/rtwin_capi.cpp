@@ -68,6 +68,7 @@ struct rtw_scene {
     std::vector<std::unique_ptr<rtw::HostMesh>> meshes;
     bool committed = false;
     int prune = 1;
+    int traversal = 1;
     RtwSceneDev* d_scene = nullptr;
     std::vector<void*> allocs;
 };
@@ -302,6 +303,19 @@ int rtw_scene_set_material(rtw_scene* scene, int shape, const rtw_material_node*
     return RTW_OK;
 }
 
+int rtw_scene_set_traversal(rtw_scene* scene, int mode)
+{
+    if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
+    if (mode != 0 && mode != 1) return fail(RTW_ERR_INVALID, "traversal must be 0 (binary preorder walk) or 1 (4-wide walk)");
+    scene->traversal = mode;
+    if (scene->committed && scene->ctx) {
+        HIP_TRY(hipSetDevice(scene->ctx->device));
+        HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+        HIP_TRY(hipMemcpy((char*)scene->d_scene + offsetof(RtwSceneDev, traversal), &scene->traversal, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return RTW_OK;
+}
+
 int rtw_scene_set_prune(rtw_scene* scene, int enabled)
 {
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
@@ -319,7 +333,7 @@ int rtw_scene_commit(rtw_scene* scene)
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
     if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
     if (!scene->ctx) {      // host-only scene: build the flattened trees for inspection, nothing to upload
-        for (auto& m : scene->meshes) rtw::build_tree(*m);
+        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_quads(*m); }
         scene->committed = true;
         return RTW_OK;
     }
@@ -328,6 +342,7 @@ int rtw_scene_commit(rtw_scene* scene)
     std::memset(h.get(), 0, sizeof(RtwSceneDev));
     h->n_shapes = (int)scene->meshes.size();
     h->prune = scene->prune;
+    h->traversal = scene->traversal;
     h->unit_table = scene->ctx->d_unit;
     h->gamma_thr = scene->ctx->d_gamma;
     h->texel_lut = scene->ctx->d_lut;
@@ -335,9 +350,14 @@ int rtw_scene_commit(rtw_scene* scene)
     for (size_t s = 0; s < scene->meshes.size(); s++) {
         rtw::HostMesh& m = *scene->meshes[s];
         rtw::build_tree(m);
+        rtw::build_quads(m);
         RtwShapeDev& d = h->shapes[s];
         int rc;
         if ((rc = upload(scene, m.nodes, &d.nodes)) != RTW_OK) return rc;
+        if (m.quad_depth <= RTW_QUAD_STACK) {
+            if ((rc = upload(scene, m.quads, &d.quads)) != RTW_OK) return rc;
+            d.n_quads = (int)m.quads.size(); d.quad_depth = m.quad_depth;
+        }
         if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
         if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
         std::vector<uint32_t> atlas;
@@ -392,6 +412,23 @@ int rtw_scene_mesh_nodes(const rtw_scene* scene, int shape, float* bounds6, int3
         if (tri) tri[i] = nd.tri >= 0 ? m.tris[(size_t)nd.tri].orig : -1;
     }
     return (int)m.nodes.size();
+}
+
+int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int32_t* child4, int max_quads)
+{
+    if (!scene || shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
+    const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    const int n = (int)m.quads.size() < max_quads ? (int)m.quads.size() : max_quads;
+    for (int i = 0; i < n; i++) {
+        const RtwQuad& q = m.quads[(size_t)i];
+        if (bounds24) std::memcpy(bounds24 + (size_t)i * 24, q.min_x, 96);
+        if (child4) for (int k = 0; k < 4; k++) {
+            const int32_t c = q.child[k];
+            child4[(size_t)i * 4 + k] = (c < 0 && c != RTW_QUAD_EMPTY) ? -1 - m.tris[(size_t)(-1 - c)].orig : c;
+        }
+    }
+    return (int)m.quads.size();
 }
 
 // ---- ray-level queries ------------------------------------------------------------------------------------
@@ -559,7 +596,12 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     hipError_t e;
     if (scene->ctx->pipeline == 1) {
         int rc = ensure_workspace(scene->ctx, rtw::pipeline_workspace_bytes(p.count, max_bounce, nullptr)); if (rc != RTW_OK) return rc;
-        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
+        int lds_quads = 0;
+        if (scene->traversal != 0 && !scene->meshes.empty() && scene->meshes[0]->quad_depth <= RTW_QUAD_STACK) {
+            lds_quads = (int)scene->meshes[0]->quads.size();
+            if (lds_quads > RTW_LDS_QUAD_BUDGET) lds_quads = 0;        // all or nothing: a larger tree is read through L2
+        }
+        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, scene->ctx->stats_enabled, scene->ctx->stream);
     } else {
         int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
         e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);

@@ -321,6 +321,77 @@ void build_tree(HostMesh& m)
 }
 
 // ---------------------------------------------------------------------------------------
+// 4-wide collapse.  A quad node stands for one internal binary node; its slots are descendants
+// of that node in left-to-right order, obtained by repeatedly replacing the internal slot with
+// the largest box by its two children while at most 4 slots result.  Testing a slot's own box is
+// enough: a ray that hits a node's box hits every ancestor's box too (the slab test is monotone
+// in the box bounds and ancestors' bounds enclose it exactly), so skipping intermediate boxes
+// cannot admit a leaf the reference would not test.
+// ---------------------------------------------------------------------------------------
+void build_quads(HostMesh& m)
+{
+    m.quads.clear(); m.quad_depth = 0;
+    if (m.nodes.empty()) return;
+    auto is_leaf = [&](int n) { return m.nodes[(size_t)n].tri >= 0; };
+    auto area = [&](int n) {
+        const RtwNode& b = m.nodes[(size_t)n];
+        const float dx = b.max_x - b.min_x, dy = b.max_y - b.min_y, dz = b.max_z - b.min_z;
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Pending { int binary_node; int depth; };
+    std::vector<Pending> queue;
+    std::vector<std::vector<int>> slots_of;          // per quad: binary nodes of its slots
+    auto make_slots = [&](int n) {
+        std::vector<int> sl;
+        if (is_leaf(n)) { sl.push_back(n); return sl; }       // a one-triangle mesh: the root is a leaf
+        const int l = n + 1, r = m.nodes[(size_t)l].skip;
+        sl = { l, r };
+        for (;;) {
+            int best = -1; float best_area = -1.0f;
+            for (size_t k = 0; k < sl.size(); k++)
+                if (!is_leaf(sl[k]) && area(sl[k]) > best_area) { best = (int)k; best_area = area(sl[k]); }
+            if (best < 0 || sl.size() + 1 > 4) break;
+            const int n2 = sl[(size_t)best], l2 = n2 + 1, r2 = m.nodes[(size_t)l2].skip;
+            sl[(size_t)best] = l2;
+            sl.insert(sl.begin() + best + 1, r2);
+        }
+        return sl;
+    };
+    queue.push_back({ 0, 1 });
+    slots_of.push_back(make_slots(0));
+    std::vector<std::vector<int>> child_quad;        // per quad, per slot: quad index or -1
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const std::vector<int> sl = slots_of[qi];
+        const int depth = queue[qi].depth;
+        if (depth > m.quad_depth) m.quad_depth = depth;
+        std::vector<int> ch(sl.size(), -1);
+        for (size_t k = 0; k < sl.size(); k++) {
+            if (is_leaf(sl[k])) continue;
+            ch[k] = (int)queue.size();
+            queue.push_back({ sl[k], depth + 1 });
+            slots_of.push_back(make_slots(sl[k]));
+        }
+        child_quad.push_back(ch);
+    }
+    m.quads.resize(queue.size());
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        RtwQuad& q = m.quads[qi];
+        for (int k = 0; k < 4; k++) {
+            q.min_x[k] = q.min_y[k] = q.min_z[k] = FLT_MAX;
+            q.max_x[k] = q.max_y[k] = q.max_z[k] = -FLT_MAX;
+            q.child[k] = RTW_QUAD_EMPTY; q.pad[k] = 0;
+        }
+        const std::vector<int>& sl = slots_of[qi];
+        for (size_t k = 0; k < sl.size(); k++) {
+            const RtwNode& b = m.nodes[(size_t)sl[k]];
+            q.min_x[k] = b.min_x; q.min_y[k] = b.min_y; q.min_z[k] = b.min_z;
+            q.max_x[k] = b.max_x; q.max_y[k] = b.max_y; q.max_z[k] = b.max_z;
+            q.child[k] = is_leaf(sl[k]) ? -1 - b.tri : child_quad[qi][k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // random stream + host-generated tables
 // ---------------------------------------------------------------------------------------
 namespace {

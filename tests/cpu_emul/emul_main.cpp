@@ -3,6 +3,7 @@
 #define RTW_HOST_EMUL 1
 #include "../../raytracerwin_amd/csrc/rtw_device.hip"
 #include "../../raytracerwin_amd/csrc/rtw_host.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -14,6 +15,7 @@ int main(int argc, char** argv)
     std::string err = rtw::load_obj(argv[1], m);
     if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 2; }
     rtw::build_tree(m);
+    rtw::build_quads(m);
     RtwRenderParams p; memset(&p, 0, sizeof p);
     p.width = atoi(argv[2]); p.height = atoi(argv[3]); p.sub_samples = atoi(argv[4]); p.max_bounce = atoi(argv[5]);
     p.world = 1; p.seed = 12345;
@@ -28,6 +30,9 @@ int main(int argc, char** argv)
     sc.unit_table = table.data(); sc.gamma_thr = thr.data(); sc.texel_lut = lut.data();
     RtwShapeDev& d = sc.shapes[0];
     d.nodes = m.nodes.data(); d.tris = m.tris.data(); d.shade = m.shade.data();
+    d.quads = m.quads.data(); d.n_quads = (int)m.quads.size(); d.quad_depth = m.quad_depth;
+    sc.traversal = argc > 9 ? atoi(argv[9]) : 1;
+    fprintf(stderr, "quads %zu depth %d\n", m.quads.size(), m.quad_depth);
     std::vector<uint32_t> atlas;
     for (size_t t = 0; t < m.textures.size() && t < RTW_DEV_MAX_TEXTURES; t++) {
         if (!m.textures[t].valid) continue;
@@ -45,9 +50,32 @@ int main(int argc, char** argv)
     const int grid = (p.count + 255) / 256;
     gridDim.x = (unsigned)grid;
     std::vector<float4> ws((size_t)grid * 256 * (size_t)p.max_bounce * 3);
+    const bool hist = getenv("RTW_EMUL_HIST") != nullptr;
+    static unsigned long long stats[8]; sc.stats = stats;
+    std::vector<unsigned> per_px_box, per_px_tri;
     for (int b = 0; b < grid; b++) {
         blockIdx.x = (unsigned)b;
-        for (int t = 0; t < 256; t++) { threadIdx.x = (unsigned)t; render_kernel<false>(&sc, accum.data(), argb.data(), ws.data(), p); }
+        for (int t = 0; t < 256; t++) {
+            threadIdx.x = (unsigned)t;
+            if (hist) {
+                const unsigned long long b0 = stats[1], t0 = stats[2];
+                render_kernel<true>(&sc, accum.data(), argb.data(), ws.data(), p);
+                per_px_box.push_back((unsigned)(stats[1] - b0)); per_px_tri.push_back((unsigned)(stats[2] - t0));
+            } else render_kernel<false>(&sc, accum.data(), argb.data(), ws.data(), p);
+        }
+    }
+    if (hist) {
+        auto report = [](const char* name, std::vector<unsigned> v) {
+            std::vector<unsigned> w; for (unsigned x : v) if (x > 1) w.push_back(x);
+            std::sort(w.begin(), w.end());
+            unsigned long long sum = 0; for (unsigned x : w) sum += x;
+            if (w.empty()) return;
+            printf("%s: paths %zu mean %.1f p50 %u p90 %u p99 %u p99.9 %u max %u\n", name, w.size(), (double)sum / w.size(),
+                   w[w.size() / 2], w[w.size() * 9 / 10], w[w.size() * 99 / 100], w[(size_t)(w.size() * 0.999)], w.back());
+        };
+        report("box tests per path", per_px_box);
+        report("tri tests per path", per_px_tri);
+        // per-wave (64 consecutive pixels) max vs mean, as the one-thread-per-pixel kernel sees it
     }
     double s = 0; for (auto& a : accum) s += a.x + a.y + a.z;
     printf("emul ok: checksum %.6f\n", s);

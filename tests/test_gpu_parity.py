@@ -190,6 +190,7 @@ def test_config2_band_vs_oracle_and_stats(ctx, oracle_mod):
     oa, ob = ofb.read()
     s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Diffuse())
     s.set_prune(0)
+    s.set_traversal(0)          # the binary preorder walk visits exactly the boxes the reference visits
     ctx.stats_enable(True)
     ctx.stats_reset()
     fb = R.Framebuffer(ctx, W, H)
@@ -312,3 +313,20 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     ctx.set_option("pipeline", 1)
     assert (bits(out[0][0]) == bits(out[1][0])).all() and (out[0][1] == out[1][1]).all()
     assert out[0][2] == out[1][2]
+
+
+@pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4), ("BlenderMonkey", 4, 6)])
+def test_quad_walk_equals_binary_walk(ctx, mesh, ns, depth):
+    """traversal=1 (4-wide, candidates gathered then triangle-tested in order) vs traversal=0 (binary preorder
+    walk in the reference's visit order), with and without pruning: same bits at 1920x1080."""
+    W, H = 1920, 1080
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse())
+    ref = None
+    for trav, prune in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        s.set_traversal(trav)
+        s.set_prune(prune)
+        a, b = render_frame(ctx, s, W, H, ns, depth, 0, 99)
+        if ref is None:
+            ref = (a, b)
+        else:
+            assert (bits(a) == bits(ref[0])).all() and (b == ref[1]).all(), (trav, prune)
