@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--prune", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--traversal", type=int, default=1)
+    ap.add_argument("--packets", type=int, default=1)
+    ap.add_argument("--path-lanes", type=int, default=16)
+    ap.add_argument("--depth", type=int, default=0, help="override the config's depth (experiments only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -156,6 +159,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     mesh, W, H, spp, depth, kind = CONFIGS[args.config]
+    if args.depth > 0:
+        depth = args.depth
     mesh_path = os.path.join(ROOT, "assets", mesh + ".obj")
     data = "synthetic frame of assets/%s.obj (byte copy of the reference's Data file)" % mesh
     if not os.path.exists(mesh_path):
@@ -167,6 +172,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = R.Context(local_rank, stream=stream.cuda_stream)
     ctx.set_option("pipeline", args.pipeline)
+    ctx.set_option("packets", args.packets)
+    ctx.set_option("path_lanes", args.path_lanes)
     scene = R.RayTracerScene(ctx)
     scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
     scene.set_prune(args.prune)
@@ -287,7 +294,7 @@ def main():
             "config": {"workload": "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s])"
                                    % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3}[args.config]),
                        "sharding": "10-row tasks round-robin over ranks, one RCCL gather of the rows after the K passes",
-                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "traversal": args.traversal},
+                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "traversal": args.traversal, "packets": args.packets, "path_lanes": args.path_lanes},
             "camera_Mrays_per_s": st["camera_rays"] / elapsed / 1e6,
             "rays_per_frame": rays_total / K,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -15,13 +15,21 @@ inline size_t level_workspace_bytes(long long work_items, int max_bounce)
     const size_t threads = (size_t)((work_items + 255) / 256) * 256;
     return threads * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
 }
-struct PipelineLayout { size_t queue_off, pend_off, counters_off, rad_off, ws_off, total; int path_quartets; };
+struct PipelineLayout { size_t queue_off, pend_off, counters_off, rad_off, hit_off, ws_off, total; int path_quartets; };
 #define RTW_MAX_PATH_QUARTETS (1 << 20)   // quartets (paths in flight) of one path_kernel launch; more paths loop
 #define RTW_PATH_BLOCK_LDS 512            // threads per block when the quads are staged in LDS
 // workspace of the compacted pipeline for a launch of `work_items` pixels (device bytes)
 size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out);
 // lds_quad_count: how many of shape 0's quads (breadth-first order) each path_kernel block stages in LDS
-int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, bool stats, hipStream_t stream);
+struct PipelineTuning {
+    int path_lanes;        // lanes per ray in the path kernel: 16, 4 or 1
+    int lds_wide_count;    // path_lanes 16: 16-wide nodes of shape 0 staged in LDS (0 = read through L2)
+    int expected_paths;    // queue length seen by the previous pass on this context, -1 = unknown
+};
+int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream);
+// device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)
+size_t pipeline_counters_offset(long long work_items, int max_bounce);
+#define RTW_LDS_WIDE_BUDGET 160   // 16-wide nodes (448 B each) that may be staged in LDS: 70 KiB -> two 256-thread blocks per CU
 #define RTW_LDS_QUAD_BUDGET 1024  // quads (128 B each) that may be staged in LDS beside the per-quartet trails and lists
 int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream);
 int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float* hits11, int* shape, int* tri, bool stats, hipStream_t stream);

@@ -19,6 +19,10 @@
 #define RTW_MAX_BOUNCE_DEV 16
 #endif
 
+#ifdef RTW_TIMING
+__device__ unsigned long long g_rtw_timing[6 * 16384];
+#endif
+
 namespace {
 
 struct f3 { float x, y, z; };
@@ -94,12 +98,16 @@ typedef __attribute__((address_space(1))) const float rtw_g_f1;
 typedef __attribute__((address_space(3))) const float rtw_l_f1;
 typedef __attribute__((address_space(3))) const uint32_t rtw_l_u1;
 typedef __attribute__((address_space(3))) uint32_t rtw_l_u1w;
+typedef __attribute__((address_space(4))) const float4 rtw_c_f4;
+// wave-uniform address in read-only memory: becomes an s_load (scalar cache), no vector memory instruction
+__device__ __forceinline__ float4 cld4(const float4* p, int i) { return ((rtw_c_f4*)p)[i]; }
 __device__ __forceinline__ float4 gld4(const float4* p, size_t i) { return ((rtw_g_f4*)p)[i]; }
 __device__ __forceinline__ float gld1(const float* p, size_t i) { return ((rtw_g_f1*)p)[i]; }
 __device__ __forceinline__ float lld1(const float* p, int i) { return ((rtw_l_f1*)p)[i]; }
 __device__ __forceinline__ uint32_t lldu(const uint32_t* p, int i) { return ((rtw_l_u1*)p)[i]; }
 __device__ __forceinline__ void lstu(uint32_t* p, int i, uint32_t v) { ((rtw_l_u1w*)p)[i] = v; }
 #else
+__device__ __forceinline__ float4 cld4(const float4* p, int i) { return p[i]; }
 __device__ __forceinline__ float4 gld4(const float4* p, size_t i) { return p[i]; }
 __device__ __forceinline__ float gld1(const float* p, size_t i) { return p[i]; }
 __device__ __forceinline__ float lld1(const float* p, int i) { return p[i]; }
@@ -150,7 +158,19 @@ __device__ __forceinline__ bool slab_exact(const Ray& r, float mnx, float mny, f
 // A ray is "tame" when every direction component is a normal number of magnitude >= FLT_EPSILON
 // and the origin is finite and moderate: then no slab axis is skipped and no NaN/inf can appear,
 // so Math::Min/Max equal v_min/v_max and the reciprocal can be hoisted out of the node loop.
+#ifdef RTW_HOST_EMUL
+static unsigned long long g_emul_tame = 0, g_emul_untame = 0;
+#endif
+__device__ __forceinline__ bool ray_is_tame_impl(const Ray& r);
 __device__ __forceinline__ bool ray_is_tame(const Ray& r)
+{
+    const bool t = ray_is_tame_impl(r);
+#ifdef RTW_HOST_EMUL
+    if (t) g_emul_tame++; else { g_emul_untame++; if (g_emul_untame < 6) fprintf(stderr, "untame ray o=(%g %g %g) d=(%g %g %g)\n", r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z); }
+#endif
+    return t;
+}
+__device__ __forceinline__ bool ray_is_tame_impl(const Ray& r)
 {
     const float big = 1.0e15f;
     return fabsf(r.d.x) >= FLT_EPSILON && fabsf(r.d.y) >= FLT_EPSILON && fabsf(r.d.z) >= FLT_EPSILON &&
@@ -233,6 +253,72 @@ __device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, co
     return any;
 }
 
+// ---- packet walk: one wave, 64 coherent rays, ONE shared position in the tree ------------------------------
+// For camera rays of neighbouring pixels.  The node index is wave-uniform (node and triangle records come
+// through scalar loads, the walk needs no per-lane stack or list), every lane tests the current box with its
+// own ray, and a subtree is entered when ANY lane's ray hits its box.  A lane only ever triangle-tests a leaf
+// whose own box its ray hits, in preorder, with its own shrinking segment -- which is all the reference's
+// result depends on (a ray that hits a box hits every enclosing box), so each lane gets the bits it would get
+// walking alone.  Lanes with `active` false (no ray, ray outside the shape bound, or not tame) just ride along.
+// EXACT: the lanes' rays are not "tame" (a near-zero direction component, NaN, ...): the box test then is the
+// reference's own form (skipped axes, Math::Min/Max ternaries), with the three reciprocals hoisted; no pruning.
+template <bool STATS, bool EXACT>
+__device__ __forceinline__ bool packet_walk(const RtwNode* nodes, const RtwTri* tris, int n_nodes, const Ray& r, bool active, bool prune,
+                                            float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
+{
+    const bool skx = near_zero(r.d.x), sky = near_zero(r.d.y), skz = near_zero(r.d.z);
+    const float ix = (EXACT && skx) ? 0.0f : 1.0f / r.d.x, iy = (EXACT && sky) ? 0.0f : 1.0f / r.d.y, iz = (EXACT && skz) ? 0.0f : 1.0f / r.d.z;
+    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+    const float4* nd4 = reinterpret_cast<const float4*>(nodes);
+    const float4* tr4 = reinterpret_cast<const float4*>(tris);
+    bool any = false;
+    int i = 0;
+    while (i < n_nodes) {
+#ifndef RTW_HOST_EMUL
+        const int iu = __builtin_amdgcn_readfirstlane(i);
+#else
+        const int iu = i;
+#endif
+        const float4 lo = cld4(nd4, 2 * iu), hi = cld4(nd4, 2 * iu + 1);
+        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+        const float x1 = (lo.x - r.o.x) * ix, x2 = (hi.x - r.o.x) * ix;
+        const float y1 = (lo.y - r.o.y) * iy, y2 = (hi.y - r.o.y) * iy;
+        const float z1 = (lo.z - r.o.z) * iz, z2 = (hi.z - r.o.z) * iz;
+        float tmin, tmax;
+        if (EXACT) {            // RRay::TestIntersectionWithAabb as written (Src/RRay.cpp:93-126)
+            tmin = -FLT_MAX; tmax = FLT_MAX;
+            if (!skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
+            if (!sky) { tmin = ref_max(tmin, ref_min(y1, y2)); tmax = ref_min(tmax, ref_max(y1, y2)); }
+            if (!skz) { tmin = ref_max(tmin, ref_min(z1, z2)); tmax = ref_min(tmax, ref_max(z1, z2)); }
+        } else {
+            tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+            tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+        }
+        bool hit = active && (tmax > tmin);
+        if (!EXACT && prune) hit = hit && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
+        if (STATS) ct.boxes += active ? 1u : 0u;
+#ifndef RTW_HOST_EMUL
+        const bool any_hit = __ballot(hit) != 0ull;
+#else
+        const bool any_hit = hit;
+#endif
+        if (leaf >= 0) {
+            if (any_hit) {
+                const float4 a = cld4(tr4, 4 * leaf), b = cld4(tr4, 4 * leaf + 1), c = cld4(tr4, 4 * leaf + 2), d = cld4(tr4, 4 * leaf + 3);
+                if (hit) {
+                    if (STATS) ct.tris++;
+                    f3 cp; float dist;
+                    if (triangle_test(r, cur_dist, a, b, c, d.x, cp, dist)) { cur_dist = dist; hit_pos = cp; hit_slot = leaf; any = true; }
+                }
+            }
+            i = skip;
+        } else {
+            i = any_hit ? iu + 1 : skip;
+        }
+    }
+    return any;
+}
+
 // ---- 4-wide walk -------------------------------------------------------------------------------------
 // Per-lane working memory in LDS: a trail of (quad, remaining-slot mask) per tree level and the list of
 // candidate leaves gathered so far, both indexed [entry * block_threads + thread] (conflict-free).
@@ -253,6 +339,16 @@ __device__ __forceinline__ TravCtx make_trav(uint32_t* lds_words)
     t.trail = lds_words; t.cand = lds_words + RTW_QUAD_STACK * 256;
     t.lds_quads = nullptr;
     t.tid = (int)threadIdx.x; t.nthr = 256; t.lane4 = 0; t.count = true;
+    return t;
+}
+// sixteen lanes per ray: owner = group of 16
+__device__ __forceinline__ TravCtx make_trav16(uint32_t* lds_words, int block_threads, const float* lds_wides)
+{
+    TravCtx t;
+    const int groups = block_threads / 16;
+    t.trail = lds_words; t.cand = lds_words + RTW_WIDE_STACK * groups;
+    t.lds_quads = lds_wides;
+    t.tid = (int)(threadIdx.x >> 4); t.nthr = groups; t.lane4 = (int)(threadIdx.x & 15u); t.count = (threadIdx.x & 15u) == 0u;
     return t;
 }
 // four lanes per ray: owner = quartet
@@ -481,6 +577,120 @@ __device__ __forceinline__ bool quad_walk4(const RtwShapeDev& sh, const TravCtx&
 }
 #endif
 
+// ---- 16-wide walk, sixteen lanes per ray ----------------------------------------------------------------
+// Same scheme as quad_walk4 with a 16-slot node per step: lane k of the group tests slot k, the hit mask is the
+// group's 16 bits of the wave ballot, candidates are triangle-tested sixteen at a time.  A ray needs ~4x fewer
+// dependent steps than with quartets, which is what matters when there are too few rays to fill the GPU.
+#ifndef RTW_HOST_EMUL
+// EXACT: for rays that are not "tame": the reference's own box test (skipped axes, Math::Min/Max), no pruning.
+template <bool STATS, bool LDSW, bool EXACT>
+__device__ __forceinline__ bool wide_walk16(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
+                                            float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
+{
+    const bool skx = near_zero(r.d.x), sky = near_zero(r.d.y), skz = near_zero(r.d.z);
+    const float ix = (EXACT && skx) ? 0.0f : 1.0f / r.d.x, iy = (EXACT && sky) ? 0.0f : 1.0f / r.d.y, iz = (EXACT && skz) ? 0.0f : 1.0f / r.d.z;
+    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+    const float* gw = reinterpret_cast<const float*>(sh.wides);
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    const int k16 = tc.lane4;                                 // lane within the group of 16
+    const int grp_shift = (int)(threadIdx.x & 48u);
+    bool any = false;
+    int sp = 0;
+    uint32_t m = 0;
+    int ch_mine = 0;
+    int q = 0;
+    bool need_node = true;
+    bool walking = true;
+    while (walking) {
+        int ncand = 0;
+        for (;;) {
+            if (need_node) {
+                float mnx, mny, mnz, mxx, mxy, mxz; int ch;
+                const int wb = q * 112 + k16;
+                if (LDSW) {
+                    mnx = lld1(tc.lds_quads, wb); mny = lld1(tc.lds_quads, wb + 16); mnz = lld1(tc.lds_quads, wb + 32);
+                    mxx = lld1(tc.lds_quads, wb + 48); mxy = lld1(tc.lds_quads, wb + 64); mxz = lld1(tc.lds_quads, wb + 80);
+                    ch = __float_as_int(lld1(tc.lds_quads, wb + 96));
+                } else {
+                    mnx = gld1(gw, (size_t)wb); mny = gld1(gw, (size_t)wb + 16); mnz = gld1(gw, (size_t)wb + 32);
+                    mxx = gld1(gw, (size_t)wb + 48); mxy = gld1(gw, (size_t)wb + 64); mxz = gld1(gw, (size_t)wb + 80);
+                    ch = __float_as_int(gld1(gw, (size_t)wb + 96));
+                }
+                const float x1 = (mnx - r.o.x) * ix, x2 = (mxx - r.o.x) * ix;
+                const float y1 = (mny - r.o.y) * iy, y2 = (mxy - r.o.y) * iy;
+                const float z1 = (mnz - r.o.z) * iz, z2 = (mxz - r.o.z) * iz;
+                float tmin, tmax;
+                if (EXACT) {
+                    tmin = -FLT_MAX; tmax = FLT_MAX;
+                    if (!skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
+                    if (!sky) { tmin = ref_max(tmin, ref_min(y1, y2)); tmax = ref_min(tmax, ref_max(y1, y2)); }
+                    if (!skz) { tmin = ref_max(tmin, ref_min(z1, z2)); tmax = ref_min(tmax, ref_max(z1, z2)); }
+                } else {
+                    tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                    tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                }
+                bool h = (tmax > tmin) && (ch != RTW_QUAD_EMPTY);
+                if (!EXACT && prune) h = h && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
+                if (STATS) ct.boxes += (ch != RTW_QUAD_EMPTY);
+                m = (uint32_t)(__ballot(h) >> grp_shift) & 0xFFFFu;
+                ch_mine = ch;
+                need_node = false;
+            }
+            int next = -1;
+            bool full = false;
+            for (;;) {
+                if (m == 0u) {
+                    if (sp == 0) break;
+                    sp--;
+                    const uint32_t e = lldu(tc.trail, sp * tc.nthr + tc.tid);
+                    q = (int)(e >> 16); m = e & 0xFFFFu;
+                    ch_mine = LDSW ? __float_as_int(lld1(tc.lds_quads, q * 112 + 96 + k16)) : __float_as_int(gld1(gw, (size_t)q * 112 + 96 + k16));
+                    continue;
+                }
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1u;
+                const int ch = __shfl(ch_mine, k, 16);
+                if (ch < 0) {
+                    lstu(tc.cand, ncand * tc.nthr + tc.tid, (uint32_t)(-1 - ch));
+                    ncand++;
+                    if (ncand == RTW_WIDE_CAND) { full = true; break; }
+                    continue;
+                }
+                next = ch;
+                break;
+            }
+            if (next >= 0) {
+                if (m != 0u) { lstu(tc.trail, sp * tc.nthr + tc.tid, ((uint32_t)q << 16) | m); sp++; }
+                q = next; need_node = true;
+                continue;
+            }
+            if (!full) walking = false;
+            break;
+        }
+        for (int j = 0; j < ncand; j += 16) {
+            const bool mine = j + k16 < ncand;
+            const int leaf = mine ? (int)lldu(tc.cand, (j + k16) * tc.nthr + tc.tid) : 0;
+            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
+            if (STATS) ct.tris += mine ? 1u : 0u;
+            int settled = -1;
+            for (;;) {
+                f3 cp = mk(0, 0, 0); float dist = 0.0f;
+                const bool acc = mine && k16 > settled && triangle_test(r, cur_dist, a, b, c, d.x, cp, dist);
+                const uint32_t am = (uint32_t)(__ballot(acc) >> grp_shift) & 0xFFFFu;
+                if (am == 0u) break;
+                const int first = __ffs((int)am) - 1;
+                cur_dist = __shfl(dist, first, 16);
+                hit_pos = mk(__shfl(cp.x, first, 16), __shfl(cp.y, first, 16), __shfl(cp.z, first, 16));
+                hit_slot = __shfl(leaf, first, 16);
+                any = true;
+                settled = first;
+            }
+        }
+    }
+    return any;
+}
+#endif
+
 // ---- RTexture::Sample (Src/Texture.cpp:23-57) on RGBA8 texels + the host LUT ---------------------
 __device__ __forceinline__ void texel_fetch(const uint32_t* __restrict__ tex, const float* __restrict__ lut, int idx, float& r, float& g, float& b, float& a)
 {
@@ -512,35 +722,12 @@ __device__ __forceinline__ void texture_sample(const uint32_t* __restrict__ texe
 }
 
 // ---- RMeshShape::TestRayIntersection (Src/MeshShape.cpp:280-332) ------------------------------------
-// LPR = lanes per ray (1, or 4 in the quartet path kernel); LDSQ = shape 0's quads are staged in LDS.
-// In a quartet the four lanes run everything but quad_walk4 redundantly on identical state; Counters
-// `walk` collects what is counted per lane (box / triangle tests), `ct` what is counted once per ray.
-template <bool STATS, int LPR, bool LDSQ>
-__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, bool first_shape, const TravCtx& tc,
-                                           const Ray& r, float seg_dist, Hit& out, int& tri_index, Counters& ct)
+// The part of RMeshShape::TestRayIntersection after the tree query (Src/MeshShape.cpp:288-327): barycentrics,
+// fast-normalised smooth normal, texture sample.
+template <bool STATS>
+__device__ __forceinline__ void mesh_finish(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, const TravCtx& tc,
+                                            f3 pos, float cur, int slot, Hit& out, int& tri_index, Counters& ct)
 {
-    float cur = seg_dist; f3 pos = mk(0, 0, 0); int slot = -1;
-    bool any;
-    Counters walk = { 0, 0, 0, 0, 0, 0 };
-    if (ray_is_tame(r)) {
-        if (sc->traversal != 0 && sh.n_quads > 0) {
-#ifndef RTW_HOST_EMUL
-            if (LPR == 4) {
-                if (LDSQ && first_shape) any = quad_walk4<STATS, true>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-                else any = quad_walk4<STATS, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
-            } else
-#endif
-                any = quad_walk<STATS>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-        } else {
-            any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, walk);
-        }
-    } else {
-        any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, walk);
-    }
-    if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
-    if (!any) return false;
-    if (!RTW_IN_RANGE(sc, 3, slot, sh.n_tris)) return false;
     if (STATS && tc.count) ct.hits++;
     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
     const float4 ta = gld4(tr4, 4 * (size_t)slot), tb = gld4(tr4, 4 * (size_t)slot + 1), tcc = gld4(tr4, 4 * (size_t)slot + 2), td = gld4(tr4, 4 * (size_t)slot + 3);
@@ -568,6 +755,51 @@ __device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, c
         if (STATS && tc.count) ct.tex++;
         texture_sample(sh.texels, sh.textures[mat], sc->texel_lut, tu, 1.0f - tv, out.color, out.alpha);
     }
+}
+
+
+// LPR = lanes per ray (1, or 4 in the quartet path kernel); LDSQ = shape 0's quads are staged in LDS.
+// In a quartet the four lanes run everything but quad_walk4 redundantly on identical state; Counters
+// `walk` collects what is counted per lane (box / triangle tests), `ct` what is counted once per ray.
+template <bool STATS, int LPR, bool LDSQ>
+__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, bool first_shape, const TravCtx& tc,
+                                           const Ray& r, float seg_dist, Hit& out, int& tri_index, Counters& ct)
+{
+    float cur = seg_dist; f3 pos = mk(0, 0, 0); int slot = -1;
+    bool any;
+    Counters walk = { 0, 0, 0, 0, 0, 0 };
+    const bool tame = ray_is_tame(r);
+#ifndef RTW_HOST_EMUL
+    if (LPR == 16 && !tame && sc->traversal != 0 && sh.n_wides > 0) {
+        if (LDSQ && first_shape) any = wide_walk16<STATS, true, true>(sh, tc, r, false, cur, pos, slot, walk);
+        else any = wide_walk16<STATS, false, true>(sh, tc, r, false, cur, pos, slot, walk);
+        if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
+    } else
+#endif
+    if (tame) {
+        if (sc->traversal != 0 && sh.n_quads > 0) {
+#ifndef RTW_HOST_EMUL
+            if (LPR == 16 && sh.n_wides > 0) {
+                if (LDSQ && first_shape) any = wide_walk16<STATS, true, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+                else any = wide_walk16<STATS, false, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
+            } else if (LPR == 4) {
+                if (LDSQ && first_shape) any = quad_walk4<STATS, true>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+                else any = quad_walk4<STATS, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
+            } else
+#endif
+                any = quad_walk<STATS>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
+        } else {
+            any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, walk);
+        }
+    } else {
+        any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, walk);
+    }
+    if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
+    if (!any) return false;
+    if (!RTW_IN_RANGE(sc, 3, slot, sh.n_tris)) return false;
+    mesh_finish<STATS>(sc, sh, tc, pos, cur, slot, out, tri_index, ct);
     return true;
 }
 
@@ -611,7 +843,8 @@ __device__ __forceinline__ uint32_t mod_table_size(uint64_t x)
 }
 __device__ __forceinline__ f3 hemisphere_direction(const RtwSceneDev* __restrict__ sc, f3 normal, PathRng& rng)
 {
-    const uint32_t idx = mod_table_size(rng.table_base + rng.table_reads);   // RMath::PseudoRandomUnitVector, per-path cursor
+    uint32_t idx = mod_table_size(rng.table_base + rng.table_reads);   // RMath::PseudoRandomUnitVector, per-path cursor
+    if (sc->debug_table_mask) idx &= (uint32_t)sc->debug_table_mask;
     rng.table_reads++;
     if (!RTW_IN_RANGE(sc, 4, idx, RTW_TABLE_SIZE)) return normal;
     const float* e = sc->unit_table;
@@ -739,7 +972,8 @@ struct LevelStore {
 };
 
 template <bool STATS, int LPR, bool LDSQ>
-__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv)
+__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv,
+                         bool resume = false, int first_shape = -1, const Hit* first_hit = nullptr)
 {
     int nlev = 0;
     f3 L = mk(0, 0, 0);
@@ -747,7 +981,9 @@ __device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, 
     for (;;) {
         if (depth == 0) { L = mk(0, 0, 0); break; }
         Hit h; int tri;
-        const int s = find_intersection<STATS, LPR, LDSQ>(sc, tc, ray, h, tri, ct);
+        int s;
+        if (resume) { s = first_shape; h = *first_hit; resume = false; }     // the scene query of the camera ray was done by the primary kernel
+        else s = find_intersection<STATS, LPR, LDSQ>(sc, tc, ray, h, tri, ct);
         if (s < 0) {                                                     // sky (Src/RayTracerScene.cpp:89-94)
             const float t = 0.5f * (ray.d.y + 1.0f);
             L = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
@@ -922,6 +1158,7 @@ struct PipeBufs {
     uint32_t* __restrict__ queue;      // path id = work_item * 4 + sub_sample
     uint32_t* __restrict__ pend;       // work items with at least one queued sample
     float4* __restrict__ rad;          // radiance per path id (only slots of pending pixels are used)
+    float4* __restrict__ hitrec;       // with primary packets: 2 x float4 per path id (position + distance, shape + leaf slot)
     uint32_t* __restrict__ counters;   // [0] queue length, [1] pending length
     float4* __restrict__ ws;           // level store of path_kernel's threads
 };
@@ -948,7 +1185,9 @@ __device__ __forceinline__ f3 sky_color(float dir_y)        // Src/RayTracerScen
     return mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
 }
 
-template <bool STATS>
+// PACKET: the camera ray's whole scene query happens here, as a packet walk of each wave's 64 neighbouring
+// pixels; only samples that HIT are queued (with their hit record), misses are finished with the sky colour.
+template <bool STATS, bool PACKET>
 __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
                                                       uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
 {
@@ -961,26 +1200,58 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
     const bool live = pixel < npix;
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     f3 s[4];
-    uint32_t queued = 0;
-    if (live) {
-        const uint32_t phase = table_phase(p.seed);
-        const int n_shapes = sc->n_shapes;
-        for (int i = 0; i < 4; i++) {
-            s[i] = mk(0, 0, 0);
-            if (i >= p.sub_samples) continue;
-            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
-            const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
-            if (STATS) ct.cams++;
-            if (p.max_bounce == 0) continue;                 // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+    uint32_t queued = 0, full_trace = 0;
+    const uint32_t phase = table_phase(p.seed);
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    for (int i = 0; i < 4; i++) {                            // wave-uniform loop: the packet walk needs the whole wave
+        s[i] = mk(0, 0, 0);
+        if (i >= p.sub_samples) continue;
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)p.pass_index, (uint32_t)i);
+        const Ray ray = camera_ray(p.width, p.height, live ? pixel : 0, i, rng);
+        if (STATS && live) ct.cams++;
+        if (p.max_bounce == 0) continue;                     // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+        if (!PACKET) {
             bool any = false;
             for (int k = 0; k < n_shapes; k++) {
                 float t0, t1;
                 any = any || slab_exact(ray, sc->shapes[k].bmin[0], sc->shapes[k].bmin[1], sc->shapes[k].bmin[2],
                                         sc->shapes[k].bmax[0], sc->shapes[k].bmax[1], sc->shapes[k].bmax[2], t0, t1);
             }
-            if (any) queued |= 1u << i;
-            else { s[i] = sky_color(ray.d.y); if (STATS) { ct.rays++; ct.boxes += (uint32_t)n_shapes; } }
+            if (live && any) queued |= 1u << i;
+            else if (live) { s[i] = sky_color(ray.d.y); if (STATS) { ct.rays++; ct.boxes += (uint32_t)n_shapes; } }
+            continue;
         }
+        // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
+        int hit_shape = -1, hit_slot = -1;
+        f3 hit_pos = mk(0, 0, 0);
+        float seg = ray.dist;
+        if (STATS && live) ct.rays++;
+        const bool tame = ray_is_tame(ray);
+        for (int k = 0; k < n_shapes; k++) {
+            const RtwShapeDev& sh = sc->shapes[k];
+            float t0, t1;
+            const bool inbox = live && slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1);
+            if (STATS && live) ct.boxes++;
+#ifndef RTW_HOST_EMUL
+            if (__ballot(inbox) == 0ull) continue;
+#endif
+            float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
+            const bool any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
+            if (any) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
+        }
+        if (!live) continue;
+        if (!tame) {            // a handful per frame (a direction component below FLT_EPSILON): the path kernel traces them from the camera
+            queued |= 1u << i; full_trace |= 1u << i;
+            if (STATS) { ct.rays--; ct.boxes -= (uint32_t)n_shapes; }
+            continue;
+        }
+        if (hit_shape < 0) { s[i] = sky_color(ray.d.y); continue; }
+        queued |= 1u << i;
+        pb.hitrec[((size_t)wi * 4 + i) * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
+        pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
+    }
+    if (live) {
         if (queued == 0) {
             f3 c = mk(0, 0, 0);
             for (int i = 0; i < 4; i++) if (i < p.sub_samples) c = c + s[i];
@@ -991,46 +1262,74 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
                 if (i < p.sub_samples && !(queued & (1u << i))) pb.rad[(size_t)wi * 4 + i] = make_float4(s[i].x, s[i].y, s[i].z, 0.0f);
         }
     }
-    for (int i = 0; i < 4; i++) wave_push(pb.queue, &pb.counters[0], (queued >> i) & 1u, (uint32_t)wi * 4u + (uint32_t)i);
+    // bit 31 of a queue entry: no hit record, trace the path from the camera ray
+    for (int i = 0; i < 4; i++) wave_push(pb.queue, &pb.counters[0], (queued >> i) & 1u, ((uint32_t)wi * 4u + (uint32_t)i) | (((full_trace >> i) & 1u) << 31));
     wave_push(pb.pend, &pb.counters[1], queued != 0, (uint32_t)wi);
     if (STATS) flush_counters(sc, ct);
 }
 
-// One quartet (4 lanes) per queued path; NT threads per block.  With LDSQ the block first stages every quad of
-// shape 0 (breadth-first array) in LDS; the per-quartet trail and candidate list live in LDS as well.
-template <bool STATS, bool LDSQ, int NT>
-__global__ __launch_bounds__(NT) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
+// One owner per queued path: a quartet (LPR = 4 lanes on one ray) or a single lane (LPR = 1); NT threads per block.
+// With LDSQ the block first stages every quad of shape 0 (breadth-first array) in LDS.  When the primary kernel has
+// already done the camera ray's scene query (p.packets), the path resumes from the stored hit record.
+template <bool STATS, bool LDSQ, int NT, int LPR>
+__global__ __launch_bounds__(NT, (LPR == 16 ? 4 : (NT <= 256 ? 4 : 2))) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
 {
 #ifdef RTW_HOST_EMUL
     (void)sc; (void)pb; (void)p; (void)lds_quad_count;
 #else
-    __shared__ uint32_t trav_words[(RTW_QUAD_STACK + RTW_CAND_CAP) * (NT / 4)];
+    __shared__ uint32_t trav_words[(LPR == 16 ? (RTW_WIDE_STACK + RTW_WIDE_CAND) : (RTW_QUAD_STACK + RTW_CAND_CAP)) * (NT / LPR)];
     extern __shared__ float lds_quads[];
     // the grid is sized for the worst case (every sample queued); blocks past the real queue leave at once
-    if (blockIdx.x * (uint32_t)(NT / 4) >= pb.counters[0]) return;
-    if (LDSQ) {
-        const float4* src = reinterpret_cast<const float4*>(sc->shapes[0].quads);
+    if (blockIdx.x * (uint32_t)(NT / LPR) >= pb.counters[0]) return;
+#ifdef RTW_TIMING
+    const unsigned long long rtw_t0 = wall_clock64();
+#endif
+    if (LDSQ) {     // lds_quad_count nodes of shape 0: quads (8 float4 each) or 16-wide nodes (28 float4 each)
+        const float4* src = LPR == 16 ? reinterpret_cast<const float4*>(sc->shapes[0].wides) : reinterpret_cast<const float4*>(sc->shapes[0].quads);
         float4* dst = reinterpret_cast<float4*>(lds_quads);
-        for (int i = (int)threadIdx.x; i < lds_quad_count * 8; i += NT) dst[i] = gld4(src, (size_t)i);
+        for (int i = (int)threadIdx.x; i < lds_quad_count * (LPR == 16 ? 28 : 8); i += NT) dst[i] = gld4(src, (size_t)i);
         __syncthreads();
     }
-    const TravCtx tc = make_trav4(trav_words, NT, LDSQ ? lds_quads : nullptr);
+    TravCtx tc;
+    if (LPR == 16) tc = make_trav16(trav_words, NT, LDSQ ? lds_quads : nullptr);
+    else if (LPR == 4) tc = make_trav4(trav_words, NT, LDSQ ? lds_quads : nullptr);
+    else { tc = make_trav(trav_words); tc.nthr = NT; }
     const uint32_t n = pb.counters[0];
-    const uint32_t nquartets = gridDim.x * (NT / 4);
-    const uint32_t gq = blockIdx.x * (NT / 4) + (threadIdx.x >> 2);
+    const uint32_t nowners = gridDim.x * (NT / LPR);
+    const uint32_t go = blockIdx.x * (NT / LPR) + (threadIdx.x / LPR);
     const int npix = p.width * p.height;
     const uint32_t phase = table_phase(p.seed);
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nquartets; lv.tid = (size_t)gq;
-    for (uint32_t q = gq; q < n; q += nquartets) {
-        const uint32_t pid = pb.queue[q];
+    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nowners; lv.tid = (size_t)go;
+    for (uint32_t q = go; q < n; q += nowners) {
+        const uint32_t qe = pb.queue[q];
+        const uint32_t pid = qe & 0x7FFFFFFFu;
         const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
         const int pixel = work_to_pixel(p, wi);
         PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
         const Ray ray = camera_ray(p.width, p.height, pixel, sub, rng);
-        const f3 L = trace_path<STATS, 4, LDSQ>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
-        if (tc.lane4 == 0) pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+        f3 L;
+        if (p.packets && !(qe >> 31)) {
+            const float4 r0 = pb.hitrec[(size_t)pid * 2], r1 = pb.hitrec[(size_t)pid * 2 + 1];
+            const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
+            Hit h; int tri_index;
+            mesh_finish<STATS>(sc, sc->shapes[hs], tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+            L = trace_path<STATS, LPR, LDSQ>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv, true, hs, &h);
+        } else {
+            L = trace_path<STATS, LPR, LDSQ>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+        }
+        if (LPR == 1 || tc.lane4 == 0) pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
     }
+#ifdef RTW_TIMING
+    {
+        unsigned mb = ct.boxes, mt = ct.tris, sb = ct.boxes, mr = ct.rays;
+        for (int o = 32; o > 0; o >>= 1) { mb = max(mb, (unsigned)__shfl_xor((int)mb, o)); mt = max(mt, (unsigned)__shfl_xor((int)mt, o)); sb += (unsigned)__shfl_xor((int)sb, o); mr = max(mr, (unsigned)__shfl_xor((int)mr, o)); }
+        if ((threadIdx.x & 63u) == 0 && blockIdx.x * (NT / 64) + (threadIdx.x >> 6) < 16384) {
+            const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+            g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = mb; g_rtw_timing[6 * w + 3] = mt; g_rtw_timing[6 * w + 4] = sb; g_rtw_timing[6 * w + 5] = mr;
+        }
+    }
+#endif
     if (STATS) flush_counters(sc, ct);
 #endif
 }
@@ -1133,13 +1432,21 @@ size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLa
     l.pend_off = l.queue_off + up(n * 4 * 4);
     l.counters_off = l.pend_off + up(n * 4);
     l.rad_off = l.counters_off + 256;
-    l.ws_off = l.rad_off + up(n * 4 * 16);
+    l.hit_off = l.rad_off + up(n * 4 * 16);
+    l.ws_off = l.hit_off + up(n * 4 * 32);
     l.total = l.ws_off + ((size_t)l.path_quartets + 256) * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
     if (out) *out = l;
     return l.total;
 }
 
-int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, bool stats, hipStream_t stream)
+size_t pipeline_counters_offset(long long work_items, int max_bounce)
+{
+    PipelineLayout l;
+    pipeline_workspace_bytes(work_items, max_bounce, &l);
+    return l.counters_off;
+}
+
+int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream)
 {
     if (p.count <= 0) return 0;
     PipelineLayout l;
@@ -1147,30 +1454,65 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     char* w = (char*)workspace;
     PipeBufs pb;
     pb.queue = (uint32_t*)(w + l.queue_off); pb.pend = (uint32_t*)(w + l.pend_off); pb.counters = (uint32_t*)(w + l.counters_off);
-    pb.rad = (float4*)(w + l.rad_off); pb.ws = (float4*)(w + l.ws_off);
+    pb.rad = (float4*)(w + l.rad_off); pb.hitrec = (float4*)(w + l.hit_off); pb.ws = (float4*)(w + l.ws_off);
     hipError_t e = hipMemsetAsync(pb.counters, 0, 16, stream);
     if (e != hipSuccess) return (int)e;
+    // Path owners (quartets / groups / lanes) to launch.  The true queue length is only known on the device;
+    // the host passes the length the previous pass had (frames of a progressive render barely differ) plus a
+    // margin.  Any shortfall is absorbed by the owners' stride loop, any excess by blocks that exit at once.
+    int owners = l.path_quartets;
+    if (tune.expected_paths >= 0) {
+        long long want = (long long)tune.expected_paths + tune.expected_paths / 4 + 1024;
+        if (want < owners) owners = (int)want;
+    }
     const int block = 256;
     const int grid = (p.count + block - 1) / block;
     int resolve_blocks = grid < 1024 ? grid : 1024;
-    if (stats) hipLaunchKernelGGL(primary_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-    else hipLaunchKernelGGL(primary_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-    if (lds_quad_count > 0) {
+    if (p.packets) {
+        if (stats) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    } else {
+        if (stats) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        else hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    }
+    if (tune.path_lanes == 16) {
+        if (tune.lds_wide_count > 0) {
+            constexpr int NT = 512;     // two blocks per CU share the staged tree between 16 waves
+            int blocks = (owners + NT / 16 - 1) / (NT / 16);
+            const size_t dyn = (size_t)tune.lds_wide_count * 448;
+            if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT, 16>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
+            else hipLaunchKernelGGL((path_kernel<false, true, NT, 16>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
+        } else {
+            constexpr int NT = 256;
+            const int blocks = (owners + NT / 16 - 1) / (NT / 16);
+            if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 16>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+            else hipLaunchKernelGGL((path_kernel<false, false, NT, 16>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        }
+    } else if (tune.path_lanes == 1) {
+        constexpr int NT = 256;
+        const int blocks = (owners + NT - 1) / NT;
+        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 1>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        else hipLaunchKernelGGL((path_kernel<false, false, NT, 1>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+    } else if (lds_quad_count > 0) {
         // small mesh: every quad of shape 0 in LDS, big blocks so that the staged tree is shared by 16 waves
         constexpr int NT = RTW_PATH_BLOCK_LDS;
-        const int blocks = (l.path_quartets + NT / 4 - 1) / (NT / 4);
+        const int blocks = (owners + NT / 4 - 1) / (NT / 4);
         const size_t dyn = (size_t)lds_quad_count * 128;
-        if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
-        else hipLaunchKernelGGL((path_kernel<false, true, NT>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
+        if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT, 4>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
+        else hipLaunchKernelGGL((path_kernel<false, true, NT, 4>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
     } else {
         constexpr int NT = 256;
-        const int blocks = (l.path_quartets + NT / 4 - 1) / (NT / 4);
-        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-        else hipLaunchKernelGGL((path_kernel<false, false, NT>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        const int blocks = (owners + NT / 4 - 1) / (NT / 4);
+        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        else hipLaunchKernelGGL((path_kernel<false, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
     }
     hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     return (int)hipGetLastError();
 }
+
+#ifdef RTW_TIMING
+int read_timing(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rtw_timing), sizeof(unsigned long long) * (size_t)n); }
+#endif
 
 int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float* hits11, int* shape, int* tri, bool stats, hipStream_t stream)
 {

@@ -33,6 +33,8 @@ struct HostMesh {
     std::vector<RtwShade> shade;       // leaf order
     std::vector<RtwQuad> quads;        // 4-wide collapse of `nodes`, BFS order
     int quad_depth = 0;
+    std::vector<RtwWide> wides;        // 16-wide collapse, BFS order
+    int wide_depth = 0;
     int max_depth = 0;
     int n_tris() const { return (int)(point_idx.size() / 3); }
 };

@@ -45,6 +45,16 @@ static_assert(sizeof(RtwQuad) == 128, "RtwQuad");
 #define RTW_QUAD_STACK 16   // deepest quad tree the LDS trail holds
 #define RTW_CAND_CAP 24     // candidate leaves gathered before their triangle tests run
 
+// 16-wide collapse of the same tree for the 16-lanes-per-ray walk: slot k of a node is tested by lane k.
+struct RtwWide {            // 7 x 64 B
+    float min_x[16], min_y[16], min_z[16];
+    float max_x[16], max_y[16], max_z[16];
+    int32_t child[16];      // same encoding as RtwQuad::child
+};
+static_assert(sizeof(RtwWide) == 448, "RtwWide");
+#define RTW_WIDE_STACK 8    // deepest 16-wide tree the trail holds
+#define RTW_WIDE_CAND 32    // candidate leaves gathered before their triangle tests run (two rounds of 16)
+
 struct RtwTexture {         // 16 B
     uint32_t offset;        // first texel in the atlas
     int32_t width, height;
@@ -65,6 +75,8 @@ struct RtwShapeDev {
     const RtwShade* shade;
     const uint32_t* texels;
     const RtwQuad* quads;           // BFS order; null / n_quads == 0 -> binary walk only
+    const RtwWide* wides;           // BFS order; null / n_wides == 0 -> no 16-lane walk
+    int32_t n_wides, wide_depth;
     float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
     int32_t n_quads, quad_depth;
     int32_t n_nodes, n_tris;
@@ -80,7 +92,7 @@ struct RtwSceneDev {
     int32_t n_shapes;
     int32_t prune;
     int32_t traversal;              // 1: 4-wide walk (default), 0: binary preorder walk (reference visit counts)
-    int32_t pad0;
+    int32_t debug_table_mask;       // timing experiments only: nonzero -> unit-table index &= mask (changes the image)
     const float* unit_table;        // 3 floats per entry
     const float* gamma_thr;         // 256
     const float* texel_lut;         // 256
@@ -94,6 +106,7 @@ struct RtwRenderParams {
     int32_t task_rows, rank, world; // world <= 1: contiguous range
     int32_t max_bounce, preview, pass_index, sub_samples;
     uint32_t seed;
+    int32_t packets;                // 1: the primary kernel does the camera rays' scene query as packet walks
 };
 
 // random-stream constants (shared with the oracle by specification, not by code)

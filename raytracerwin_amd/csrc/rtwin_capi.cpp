@@ -23,6 +23,10 @@ static_assert(sizeof(rtw_material_node) == sizeof(RtwMaterialNode), "material no
 static_assert(RTW_MAX_BOUNCE == RTW_MAX_BOUNCE_DEV, "bounce limit");
 static_assert(RTW_UNIT_TABLE_SIZE == RTW_TABLE_SIZE, "table size");
 
+#ifdef RTW_TIMING
+namespace rtw { int read_timing(unsigned long long* out, int n); }
+#endif
+
 namespace {
 
 thread_local std::string t_error;
@@ -60,7 +64,15 @@ struct rtw_context {
     bool stats_enabled = false;
     void* d_workspace = nullptr;        // per-launch queues / level store of the bounce recursion (grown on demand)
     size_t workspace_bytes = 0;
-    int pipeline = 1;                   // 1 = compacted three-launch pipeline (default), 0 = one kernel, one thread per pixel
+    int pipeline = 1;                   // 1 = primary / path / resolve launches (default), 0 = one kernel, one thread per pixel
+    int packets = 1;                    // pipeline 1: camera rays traced as 64-ray packets inside the primary kernel
+    int path_lanes = 16;                // pipeline 1: lanes per ray in the path kernel (16, 4 or 1)
+    uint32_t* h_counters = nullptr;     // pinned: queue / pending lengths copied back after each pass
+    hipEvent_t counters_event = nullptr;// recorded after that copy; the value is only read once the event has completed
+    bool counters_pending = false;
+    long long counters_shape = -1;      // launch shape (work items, samples) the copy in flight belongs to
+    long long known_shape = -1;         // launch shape of known_paths
+    int known_paths = -1;               // queue length of the latest pass whose copy has completed
 };
 
 struct rtw_scene {
@@ -135,6 +147,9 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipMalloc((void**)&c->d_lut, sizeof lut));
     HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    HIP_TRY(hipHostMalloc((void**)&c->h_counters, 16, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&c->counters_event, hipEventDisableTiming));
+    c->h_counters[0] = c->h_counters[1] = c->h_counters[2] = c->h_counters[3] = 0;
     HIP_TRY(hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)));
     *out = c.release();
@@ -148,6 +163,8 @@ int rtw_context_destroy(rtw_context* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_unit); (void)hipFree(ctx->d_workspace); (void)hipFree(ctx->d_gamma); (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_stats);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->counters_event) (void)hipEventDestroy(ctx->counters_event);
     delete ctx;
     return RTW_OK;
 }
@@ -167,6 +184,12 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "pipeline") == 0) {
         if (value != 0 && value != 1) return fail(RTW_ERR_INVALID, "pipeline must be 0 or 1");
         ctx->pipeline = value;
+        return RTW_OK;
+    }
+    if (std::strcmp(name, "packets") == 0) { ctx->packets = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "path_lanes") == 0) {
+        if (value != 1 && value != 4 && value != 16) return fail(RTW_ERR_INVALID, "path_lanes must be 1, 4 or 16");
+        ctx->path_lanes = value;
         return RTW_OK;
     }
     return fail(RTW_ERR_INVALID, std::string("unknown option ") + name);
@@ -343,6 +366,7 @@ int rtw_scene_commit(rtw_scene* scene)
     h->n_shapes = (int)scene->meshes.size();
     h->prune = scene->prune;
     h->traversal = scene->traversal;
+    if (const char* dm = std::getenv("RTW_DEBUG_TABLE_MASK")) h->debug_table_mask = (int32_t)std::strtol(dm, nullptr, 0);
     h->unit_table = scene->ctx->d_unit;
     h->gamma_thr = scene->ctx->d_gamma;
     h->texel_lut = scene->ctx->d_lut;
@@ -357,6 +381,10 @@ int rtw_scene_commit(rtw_scene* scene)
         if (m.quad_depth <= RTW_QUAD_STACK) {
             if ((rc = upload(scene, m.quads, &d.quads)) != RTW_OK) return rc;
             d.n_quads = (int)m.quads.size(); d.quad_depth = m.quad_depth;
+        }
+        if (m.wide_depth <= RTW_WIDE_STACK && m.wides.size() < 65536) {
+            if ((rc = upload(scene, m.wides, &d.wides)) != RTW_OK) return rc;
+            d.n_wides = (int)m.wides.size(); d.wide_depth = m.wide_depth;
         }
         if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
         if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
@@ -594,14 +622,38 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     p.width = fb->width; p.height = fb->height;
     p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
     hipError_t e;
-    if (scene->ctx->pipeline == 1) {
+    if (scene->ctx->pipeline >= 1) {
         int rc = ensure_workspace(scene->ctx, rtw::pipeline_workspace_bytes(p.count, max_bounce, nullptr)); if (rc != RTW_OK) return rc;
         int lds_quads = 0;
-        if (scene->traversal != 0 && !scene->meshes.empty() && scene->meshes[0]->quad_depth <= RTW_QUAD_STACK) {
+        if (scene->ctx->path_lanes == 4 && scene->traversal != 0 && !scene->meshes.empty() && scene->meshes[0]->quad_depth <= RTW_QUAD_STACK) {
             lds_quads = (int)scene->meshes[0]->quads.size();
             if (lds_quads > RTW_LDS_QUAD_BUDGET) lds_quads = 0;        // all or nothing: a larger tree is read through L2
         }
-        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, scene->ctx->stats_enabled, scene->ctx->stream);
+        rtw::PipelineTuning tune;
+        tune.path_lanes = scene->ctx->path_lanes;
+        tune.lds_wide_count = 0;
+        if (tune.path_lanes == 16) {
+            const rtw::HostMesh* m0 = scene->meshes.empty() ? nullptr : scene->meshes[0].get();
+            if (!m0 || m0->wides.empty() || m0->wide_depth > RTW_WIDE_STACK || m0->wides.size() >= 65536 || scene->traversal == 0) tune.path_lanes = 4;
+            else if ((int)m0->wides.size() <= RTW_LDS_WIDE_BUDGET) tune.lds_wide_count = (int)m0->wides.size();
+        }
+        if (tune.path_lanes != 4) lds_quads = 0;
+        // queue length of the previous pass with the same launch shape (a stale or missing value only costs speed)
+        rtw_context* cx = scene->ctx;
+        const long long shape = (long long)p.count * 64 + sub_samples;
+        if (cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
+            cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
+        }
+        tune.expected_paths = (cx->known_shape == shape) ? cx->known_paths : -1;
+        p.packets = (scene->ctx->packets != 0 && scene->traversal != 0) ? 1 : 0;
+        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
+        if (e == hipSuccess && !cx->counters_pending) {     // one copy in flight at a time; its value is used once it has landed
+            const size_t off = rtw::pipeline_counters_offset(p.count, max_bounce);
+            if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + off, 16, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
+                hipEventRecord(cx->counters_event, cx->stream) == hipSuccess) {
+                cx->counters_pending = true; cx->counters_shape = shape;
+            }
+        }
     } else {
         int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
         e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
@@ -670,6 +722,10 @@ int rtw_stats_get(rtw_context* ctx, rtw_stats* out)
     out->rays = h[0]; out->box_tests = h[1]; out->tri_tests = h[2]; out->shaded_hits = h[3]; out->tex_samples = h[4]; out->camera_rays = h[5];
     return RTW_OK;
 }
+
+#ifdef RTW_TIMING
+int rtw_debug_read_timing(unsigned long long* out, int n) { return rtw::read_timing(out, n); }
+#endif
 
 // ---- tables + file helpers (host only, no device needed) ------------------------------------------------------------
 uint32_t rtw_rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter) { return rtw::rand31(seed, pixel, sample, counter); }

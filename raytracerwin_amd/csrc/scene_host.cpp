@@ -328,67 +328,85 @@ void build_tree(HostMesh& m)
 // in the box bounds and ancestors' bounds enclose it exactly), so skipping intermediate boxes
 // cannot admit a leaf the reference would not test.
 // ---------------------------------------------------------------------------------------
-void build_quads(HostMesh& m)
+namespace {
+// slots (binary nodes, left to right) of every wide node, breadth-first; children[q][k] = wide index or -1
+struct Collapsed { std::vector<std::vector<int>> slots, children; int depth = 0; };
+
+Collapsed collapse_tree(const HostMesh& m, size_t width)
 {
-    m.quads.clear(); m.quad_depth = 0;
-    if (m.nodes.empty()) return;
+    Collapsed out;
+    if (m.nodes.empty()) return out;
     auto is_leaf = [&](int n) { return m.nodes[(size_t)n].tri >= 0; };
-    auto area = [&](int n) {
-        const RtwNode& b = m.nodes[(size_t)n];
-        const float dx = b.max_x - b.min_x, dy = b.max_y - b.min_y, dz = b.max_z - b.min_z;
-        return dx * dy + dy * dz + dz * dx;
-    };
-    struct Pending { int binary_node; int depth; };
-    std::vector<Pending> queue;
-    std::vector<std::vector<int>> slots_of;          // per quad: binary nodes of its slots
+    // weight of a slot = leaves below it (a full binary tree in preorder: subtree of n spans [n, skip))
+    auto area = [&](int n) { return (float)((m.nodes[(size_t)n].skip - n + 1) / 2); };
     auto make_slots = [&](int n) {
         std::vector<int> sl;
         if (is_leaf(n)) { sl.push_back(n); return sl; }       // a one-triangle mesh: the root is a leaf
         const int l = n + 1, r = m.nodes[(size_t)l].skip;
         sl = { l, r };
+        // a subtree that fits one wide node is kept whole (it becomes a full node of leaves one level down)
+        // unless the node being built fits entirely; only larger subtrees are split here
+        const bool fits = area(n) <= (float)width;
         for (;;) {
             int best = -1; float best_area = -1.0f;
             for (size_t k = 0; k < sl.size(); k++)
-                if (!is_leaf(sl[k]) && area(sl[k]) > best_area) { best = (int)k; best_area = area(sl[k]); }
-            if (best < 0 || sl.size() + 1 > 4) break;
+                if (!is_leaf(sl[k]) && (fits || area(sl[k]) > (float)width) && area(sl[k]) > best_area) { best = (int)k; best_area = area(sl[k]); }
+            if (best < 0 || sl.size() + 1 > width) break;
             const int n2 = sl[(size_t)best], l2 = n2 + 1, r2 = m.nodes[(size_t)l2].skip;
             sl[(size_t)best] = l2;
             sl.insert(sl.begin() + best + 1, r2);
         }
         return sl;
     };
-    queue.push_back({ 0, 1 });
-    slots_of.push_back(make_slots(0));
-    std::vector<std::vector<int>> child_quad;        // per quad, per slot: quad index or -1
-    for (size_t qi = 0; qi < queue.size(); qi++) {
-        const std::vector<int> sl = slots_of[qi];
-        const int depth = queue[qi].depth;
-        if (depth > m.quad_depth) m.quad_depth = depth;
+    std::vector<int> depth_of;
+    out.slots.push_back(make_slots(0));
+    depth_of.push_back(1);
+    for (size_t qi = 0; qi < out.slots.size(); qi++) {
+        const std::vector<int> sl = out.slots[qi];
+        if (depth_of[qi] > out.depth) out.depth = depth_of[qi];
         std::vector<int> ch(sl.size(), -1);
         for (size_t k = 0; k < sl.size(); k++) {
             if (is_leaf(sl[k])) continue;
-            ch[k] = (int)queue.size();
-            queue.push_back({ sl[k], depth + 1 });
-            slots_of.push_back(make_slots(sl[k]));
+            ch[k] = (int)out.slots.size();
+            out.slots.push_back(make_slots(sl[k]));
+            depth_of.push_back(depth_of[qi] + 1);
         }
-        child_quad.push_back(ch);
+        out.children.push_back(ch);
     }
-    m.quads.resize(queue.size());
-    for (size_t qi = 0; qi < queue.size(); qi++) {
-        RtwQuad& q = m.quads[qi];
-        for (int k = 0; k < 4; k++) {
+    return out;
+}
+
+template <typename Node, int W>
+void fill_wide(const HostMesh& m, const Collapsed& c, std::vector<Node>& dst)
+{
+    dst.resize(c.slots.size());
+    for (size_t qi = 0; qi < c.slots.size(); qi++) {
+        Node& q = dst[qi];
+        std::memset(&q, 0, sizeof(Node));
+        for (int k = 0; k < W; k++) {
             q.min_x[k] = q.min_y[k] = q.min_z[k] = FLT_MAX;
             q.max_x[k] = q.max_y[k] = q.max_z[k] = -FLT_MAX;
-            q.child[k] = RTW_QUAD_EMPTY; q.pad[k] = 0;
+            q.child[k] = RTW_QUAD_EMPTY;
         }
-        const std::vector<int>& sl = slots_of[qi];
+        const std::vector<int>& sl = c.slots[qi];
         for (size_t k = 0; k < sl.size(); k++) {
             const RtwNode& b = m.nodes[(size_t)sl[k]];
             q.min_x[k] = b.min_x; q.min_y[k] = b.min_y; q.min_z[k] = b.min_z;
             q.max_x[k] = b.max_x; q.max_y[k] = b.max_y; q.max_z[k] = b.max_z;
-            q.child[k] = is_leaf(sl[k]) ? -1 - b.tri : child_quad[qi][k];
+            q.child[k] = b.tri >= 0 ? -1 - b.tri : c.children[qi][k];
         }
     }
+}
+}  // namespace
+
+void build_quads(HostMesh& m)
+{
+    const Collapsed c4 = collapse_tree(m, 4);
+    fill_wide<RtwQuad, 4>(m, c4, m.quads);
+    m.quad_depth = c4.depth;
+    const Collapsed c16 = collapse_tree(m, 16);
+    fill_wide<RtwWide, 16>(m, c16, m.wides);
+    m.wide_depth = c16.depth;
 }
 
 // ---------------------------------------------------------------------------------------

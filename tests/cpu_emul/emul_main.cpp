@@ -5,6 +5,7 @@
 #include "../../raytracerwin_amd/csrc/rtw_host.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -78,6 +79,6 @@ int main(int argc, char** argv)
         // per-wave (64 consecutive pixels) max vs mean, as the one-thread-per-pixel kernel sees it
     }
     double s = 0; for (auto& a : accum) s += a.x + a.y + a.z;
-    printf("emul ok: checksum %.6f\n", s);
+    printf("emul ok: checksum %.6f  tame %llu untame %llu\n", s, g_emul_tame, g_emul_untame);
     return 0;
 }

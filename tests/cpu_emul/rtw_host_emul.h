@@ -3,6 +3,7 @@
 // (GPU sanitizers are not available on the pool).  Never linked into librtwin.so.
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #define __device__

@@ -303,16 +303,23 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     W, H = 1280, 720
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
     out = []
-    for mode in (0, 1):
+    for mode, packets, lanes in ((0, 0, 4), (1, 0, 4), (1, 0, 1), (1, 1, 4), (1, 1, 1), (1, 0, 16), (1, 1, 16)):
         ctx.set_option("pipeline", mode)
+        ctx.set_option("packets", packets)
+        ctx.set_option("path_lanes", lanes)
         ctx.stats_enable(True)
         ctx.stats_reset()
         a, b = render_frame(ctx, s, W, H, ns, depth, preview, 4321, 0, 2)
         out.append((a, b, ctx.stats()))
         ctx.stats_enable(False)
     ctx.set_option("pipeline", 1)
-    assert (bits(out[0][0]) == bits(out[1][0])).all() and (out[0][1] == out[1][1]).all()
-    assert out[0][2] == out[1][2]
+    ctx.set_option("packets", 1)
+    ctx.set_option("path_lanes", 16)
+    keys = ("rays", "shaded_hits", "tex_samples", "camera_rays")     # box / triangle test counts depend on the walk
+    for o in out[1:]:
+        assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
+        assert [out[0][2][k] for k in keys] == [o[2][k] for k in keys]
+    assert out[0][2] == out[1][2] == out[2][2]
 
 
 @pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4), ("BlenderMonkey", 4, 6)])
