@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--traversal", type=int, default=1)
     ap.add_argument("--packets", type=int, default=1)
     ap.add_argument("--path-lanes", type=int, default=16)
+    ap.add_argument("--path-variant", type=int, default=2)
     ap.add_argument("--depth", type=int, default=0, help="override the config's depth (experiments only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -174,6 +175,7 @@ def main():
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("packets", args.packets)
     ctx.set_option("path_lanes", args.path_lanes)
+    ctx.set_option("path_variant", args.path_variant)
     scene = R.RayTracerScene(ctx)
     scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
     scene.set_prune(args.prune)
@@ -185,10 +187,7 @@ def main():
         argb = torch.zeros(npix, dtype=torch.int32, device=dev)
     fb = R.Framebuffer(ctx, W, H, accum.data_ptr(), argb.data_ptr())
 
-    # rows this rank owns (10-row tasks dealt round-robin)
-    n_tasks = (H + TASK_ROWS - 1) // TASK_ROWS
-    my_rows = np.concatenate([np.arange(t * TASK_ROWS, min((t + 1) * TASK_ROWS, H)) for t in range(rank, n_tasks, world)])
-    rows_per_rank = [sum(min((t + 1) * TASK_ROWS, H) - t * TASK_ROWS for t in range(r, n_tasks, world)) for r in range(world)]
+    from raytracerwin_amd import sharding
 
     def step(i):
         scene.render_tasks(fb, TASK_ROWS, rank, world, depth, None, i, spp, SEED)
@@ -217,24 +216,9 @@ def main():
             step(i)
         ev1.record(stream)
         if world > 1:
-            # one exchange: every rank's rows of (accumulator, ARGB) to rank 0 over RCCL
-            idx = torch.from_numpy(my_rows).to(dev)
-            loc_a = accum.view(H, W * 4).index_select(0, idx).contiguous()
-            loc_c = argb.view(H, W).index_select(0, idx).contiguous()
-            if rank == 0:
-                ga = [torch.empty(rows_per_rank[r], W * 4, dtype=torch.float32, device=dev) for r in range(world)]
-                gc = [torch.empty(rows_per_rank[r], W, dtype=torch.int32, device=dev) for r in range(world)]
-            else:
-                ga = gc = None
-            dist.gather(loc_a, ga, dst=0)
-            dist.gather(loc_c, gc, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    rows = np.concatenate([np.arange(t * TASK_ROWS, min((t + 1) * TASK_ROWS, H)) for t in range(r, n_tasks, world)])
-                    ridx = torch.from_numpy(rows).to(dev)
-                    accum.view(H, W * 4).index_copy_(0, ridx, ga[r])
-                    argb.view(H, W).index_copy_(0, ridx, gc[r])
-                gathered = True
+            # the one exchange of the path: every rank's rows of (accumulator, ARGB) to rank 0 over RCCL
+            sharding.gather_rows([accum.view(H, W * 4), argb.view(H, W)], H, TASK_ROWS, rank, world, dist, dev)
+            gathered = True
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K           # HIP events on the launch stream: average render-kernel duration
@@ -259,6 +243,19 @@ def main():
             a2 = fb2.read_float()
             a2[:, 3] = a2[:, 3].astype(np.int32).view(np.float32)      # count back to int bits
             verified = bool((a2.view(np.uint32).ravel() == final_accum).all() and (fb2.resolve_argb().view(np.int32) == final_argb).all())
+        # per-kernel durations: HIP events recorded by the library on the launch stream around the three kernels of
+        # a pass (untimed extra passes on the scratch framebuffer; the timed region above stays exactly K steps)
+        ctx.stats_enable(False)
+        ctx.set_option("kernel_timing", 1)
+        kms = []
+        if args.pipeline == 1:
+            for i in range(30):
+                R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, K + i, spp, SEED)
+                if i >= 5:
+                    kms.append(ctx.last_pass_kernel_ms())
+        ctx.set_option("kernel_timing", 0)
+        ctx.stats_enable(True)
+        kernel_parts = [float(np.mean([k[j] for k in kms])) for j in range(3)] if kms else None
         # reference-faithful visit counts (un-pruned order) of ONE pass for the algorithmic byte count
         scene.set_prune(0)
         scene.set_traversal(0)
@@ -278,7 +275,10 @@ def main():
         value = rays_total / elapsed / 1e6
         alg_bytes = algorithmic_bytes(st_ref, npix) / world
         run_bytes = algorithmic_bytes(st_run, npix) / world
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # the three launches of one rtw_render_* call are priced together ("render pass"); at N=1 their event
+        # durations are summed, for N>1 the whole-loop event time per step is used
+        pass_ms = sum(kernel_parts) if (kernel_parts and world == 1) else kernel_ms
+        achieved = alg_bytes / (pass_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tp) and world == 1:
@@ -298,7 +298,11 @@ def main():
             "camera_Mrays_per_s": st["camera_rays"] / elapsed / 1e6,
             "rays_per_frame": rays_total / K,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "render_kernel", "kernel_ms": kernel_ms,
+                         "traffic": traffic,
+                         "kernel": "render pass = primary_kernel + path_kernel + resolve_kernel (one rtw_render_tasks call)" if args.pipeline == 1 else "render_kernel",
+                         "kernel_ms": pass_ms,
+                         "kernels_ms": dict(zip(("primary_kernel", "path_kernel", "resolve_kernel"), kernel_parts)) if kernel_parts else None,
+                         "loop_ms_per_step_hip_events": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "executed_bytes_per_launch": run_bytes,
                          "counters_per_frame_reference_order": st_ref, "counters_per_frame_as_run": st_run},

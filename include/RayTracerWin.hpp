@@ -1,0 +1,243 @@
+// RayTracerWin.hpp -- header-only C++ facade over the C ABI (include/rtwin.h) that keeps the reference's
+// names for the hot path, so that SetupScene-style code and the image-write call of
+// aosyang/RayTracerWin compile against librtwin.so with the same spelling:
+//
+//     RayTracerScene::AddShape(RMeshShape::Create(path), MakeUnique<SurfaceMaterial_*>(...))
+//                                                     Src/RayTracerScene.cpp:25, Src/MeshShape.h:23
+//     RayTracerScene::FindIntersectionWithScene       Src/RayTracerScene.cpp:99
+//     ThreadWorker_Render(begin, end, MaxBounceCount, RenderOption)   Src/RayTracerProgram.cpp:131
+//     RTexture::SaveBufferToPNG                       Src/Texture.cpp:201
+//     MakePixelColor / LinearToGamma / MakeUint32Color / GetUint32Color*   Src/ColorBuffer.h:34-109
+//
+// What differs from the reference, on purpose: the scene, the frame size and the random seed are explicit
+// (the reference reaches them through globals and compile-time constants), errors are reported (exceptions
+// carrying rtw_last_error()) instead of being logged and ignored, and nothing here runs on the CPU.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rtwin.h"
+
+typedef unsigned int UINT32;
+typedef UINT32 Pixel;
+
+class RVec3 {
+public:
+    float x, y, z;
+    RVec3() : x(0.0f), y(0.0f), z(0.0f) {}
+    RVec3(float _x, float _y, float _z) : x(_x), y(_y), z(_z) {}
+};
+
+struct RtwFailure : std::runtime_error {
+    int code;
+    RtwFailure(int c) : std::runtime_error(std::string("librtwin: ") + rtw_last_error()), code(c) {}
+};
+inline void RtwCheck(int rc) { if (rc < 0) throw RtwFailure(rc); }
+
+// ---- Src/ColorBuffer.h ---------------------------------------------------------------------------------------
+inline UINT32 MakeUint32Color(unsigned char r, unsigned char g, unsigned char b, unsigned char a) { return (UINT32)(a << 24 | r << 16 | g << 8 | b); }
+inline unsigned char GetUint32ColorRed(UINT32 c) { return (unsigned char)((c >> 16) & 0xFF); }
+inline unsigned char GetUint32ColorGreen(UINT32 c) { return (unsigned char)((c >> 8) & 0xFF); }
+inline unsigned char GetUint32ColorBlue(UINT32 c) { return (unsigned char)(c & 0xFF); }
+inline RVec3 LinearToGamma(const RVec3& c) { const float e = 1.0f / 2.2f; return RVec3(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+inline RVec3 GammaToLinear(const RVec3& c) { const float e = 2.2f; return RVec3(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+inline UINT32 MakePixelColor(const RVec3& c)
+{
+    auto q = [](float v) { v = v > 0.0f ? v : 0.0f; v = v < 1.0f ? v : 1.0f; return (int)(v * 255); };
+    return MakeUint32Color((unsigned char)q(c.x), (unsigned char)q(c.y), (unsigned char)q(c.z), 255);
+}
+
+// ---- Src/SurfaceMaterials.h: the same constructors, flattened into rtw_material_node[] -------------------------------
+class ISurfaceMaterial {
+public:
+    virtual ~ISurfaceMaterial() {}
+    virtual int Flatten(std::vector<rtw_material_node>& out) const = 0;
+protected:
+    static rtw_material_node Node(int type, const RVec3& c, float param, int a = 0, int b = 0)
+    {
+        rtw_material_node n; n.type = type; n.r = c.x; n.g = c.y; n.b = c.z; n.param = param; n.child_a = a; n.child_b = b; n.pad = 0;
+        return n;
+    }
+};
+class RtwLeafMaterial : public ISurfaceMaterial {
+public:
+    int Flatten(std::vector<rtw_material_node>& out) const override { out.push_back(Node(Type, Color, Param)); return (int)out.size() - 1; }
+protected:
+    RtwLeafMaterial(int type, const RVec3& c, float param) : Type(type), Color(c), Param(param) {}
+private:
+    int Type; RVec3 Color; float Param;
+};
+class SurfaceMaterial_Diffuse : public RtwLeafMaterial {
+public:
+    SurfaceMaterial_Diffuse(const RVec3 InAlbedo = RVec3(1.0f, 1.0f, 1.0f)) : RtwLeafMaterial(RTW_MAT_DIFFUSE, InAlbedo, 0.0f) {}
+};
+class SurfaceMaterial_DiffuseChecker : public RtwLeafMaterial {
+public:
+    SurfaceMaterial_DiffuseChecker(const RVec3 InAlbedo = RVec3(1.0f, 1.0f, 1.0f), float InPatternSize = 5.0f) : RtwLeafMaterial(RTW_MAT_DIFFUSE_CHECKER, InAlbedo, InPatternSize) {}
+};
+class SurfaceMaterial_Reflective : public RtwLeafMaterial {
+public:
+    SurfaceMaterial_Reflective(const RVec3 InAlbedo = RVec3(1.0f, 1.0f, 1.0f), float InFuzziness = 0.0f) : RtwLeafMaterial(RTW_MAT_REFLECTIVE, InAlbedo, InFuzziness) {}
+};
+class SurfaceMaterial_Emissive : public RtwLeafMaterial {
+public:
+    SurfaceMaterial_Emissive(const RVec3 InColor) : RtwLeafMaterial(RTW_MAT_EMISSIVE, InColor, 0.0f) {}
+};
+class SurfaceMaterial_Null : public RtwLeafMaterial {
+public:
+    SurfaceMaterial_Null() : RtwLeafMaterial(RTW_MAT_NULL, RVec3(0.0f, 0.0f, 0.0f), 0.0f) {}
+};
+
+class SurfaceMaterial_Blend : public ISurfaceMaterial {
+public:
+    SurfaceMaterial_Blend(std::unique_ptr<ISurfaceMaterial> InMaterialA, std::unique_ptr<ISurfaceMaterial> InMaterialB, float InBlendFactor)
+        : A(std::move(InMaterialA)), B(std::move(InMaterialB)), Factor(InBlendFactor) {}
+    int Flatten(std::vector<rtw_material_node>& out) const override
+    {
+        const int me = (int)out.size();
+        out.push_back(Node(RTW_MAT_BLEND, RVec3(), Factor));
+        const int ia = A->Flatten(out), ib = B->Flatten(out);       // may reallocate `out`: index afterwards
+        out[(size_t)me].child_a = ia; out[(size_t)me].child_b = ib;
+        return me;
+    }
+private:
+    std::unique_ptr<ISurfaceMaterial> A, B; float Factor;
+};
+class SurfaceMaterial_Combine : public ISurfaceMaterial {
+public:
+    SurfaceMaterial_Combine(std::unique_ptr<ISurfaceMaterial> InMaterialA, std::unique_ptr<ISurfaceMaterial> InMaterialB)
+        : A(std::move(InMaterialA)), B(std::move(InMaterialB)) {}
+    int Flatten(std::vector<rtw_material_node>& out) const override
+    {
+        const int me = (int)out.size();
+        out.push_back(Node(RTW_MAT_COMBINE, RVec3(), 0.0f));
+        const int ia = A->Flatten(out), ib = B->Flatten(out);
+        out[(size_t)me].child_a = ia; out[(size_t)me].child_b = ib;
+        return me;
+    }
+private:
+    std::unique_ptr<ISurfaceMaterial> A, B;
+};
+
+template <typename T, typename... Args>
+std::unique_ptr<T> MakeUnique(Args&&... args) { return std::unique_ptr<T>(new T(std::forward<Args>(args)...)); }
+
+// ---- Src/RRay.h ---------------------------------------------------------------------------------------------------------
+struct RayHitResult {
+    RVec3 HitPosition, HitNormal; float Distance; RVec3 SampledColor; float SampledAlpha;
+    RayHitResult() : Distance(0.0f), SampledColor(1.0f, 1.0f, 1.0f), SampledAlpha(1.0f) {}
+};
+class RRay {
+public:
+    RVec3 Origin, Direction; float Distance;
+    RRay() : Distance(0.0f) {}
+    RRay(const RVec3& o, const RVec3& d, float dist) : Origin(o), Direction(d), Distance(dist) {}
+};
+struct RenderOption { bool UseBaseColor; RenderOption() : UseBaseColor(false) {} };
+
+// ---- Src/Shapes.h / Src/MeshShape.h ----------------------------------------------------------------------------------------
+class RShape {
+public:
+    virtual ~RShape() {}
+    virtual int AddTo(rtw_scene* scene) const = 0;
+};
+class RMeshShape : public RShape {
+public:
+    explicit RMeshShape(const std::string& Filename) : Path(Filename) {}
+    static std::unique_ptr<RMeshShape> Create(const std::string& Filename) { return std::unique_ptr<RMeshShape>(new RMeshShape(Filename)); }
+    int AddTo(rtw_scene* scene) const override { int idx = -1; RtwCheck(rtw_scene_add_mesh_obj(scene, Path.c_str(), &idx)); return idx; }
+private:
+    std::string Path;
+};
+
+// ---- device context + frame buffers (accuBuffer[] / bitcolor[], Src/RayTracerProgram.cpp:49,77) ----------------------------------
+class RtwDevice {
+public:
+    explicit RtwDevice(int device = 0) : Ctx(nullptr) { RtwCheck(rtw_context_create(device, &Ctx)); }
+    ~RtwDevice() { rtw_context_destroy(Ctx); }
+    rtw_context* Get() const { return Ctx; }
+    void Synchronize() { RtwCheck(rtw_context_synchronize(Ctx)); }
+private:
+    RtwDevice(const RtwDevice&); RtwDevice& operator=(const RtwDevice&);
+    rtw_context* Ctx;
+};
+class ColorBuffer {
+public:
+    ColorBuffer(RtwDevice& dev, int width, int height) : Fb(nullptr), Width(width), Height(height) { RtwCheck(rtw_framebuffer_create(dev.Get(), width, height, &Fb)); }
+    ~ColorBuffer() { rtw_framebuffer_destroy(Fb); }
+    rtw_framebuffer* Get() const { return Fb; }
+    int bitmapWidth() const { return Width; }
+    int bitmapHeight() const { return Height; }
+    std::vector<Pixel> bitcolor() { std::vector<Pixel> p((size_t)Width * Height); RtwCheck(rtw_framebuffer_resolve_argb(Fb, p.data())); return p; }
+    std::vector<float> accuBuffer() { std::vector<float> a((size_t)Width * Height * 4); RtwCheck(rtw_framebuffer_read_float(Fb, a.data())); return a; }
+private:
+    ColorBuffer(const ColorBuffer&); ColorBuffer& operator=(const ColorBuffer&);
+    rtw_framebuffer* Fb; int Width, Height;
+};
+
+// ---- Src/RayTracerScene.h --------------------------------------------------------------------------------------------------------
+class RayTracerScene {
+public:
+    explicit RayTracerScene(RtwDevice& dev) : Scene(nullptr), Committed(false) { RtwCheck(rtw_scene_create(dev.Get(), &Scene)); }
+    ~RayTracerScene() { rtw_scene_destroy(Scene); }
+    void AddShape(std::unique_ptr<RShape> Shape, std::unique_ptr<ISurfaceMaterial> SurfaceMaterial)
+    {
+        const int idx = Shape->AddTo(Scene);
+        if (SurfaceMaterial) {
+            std::vector<rtw_material_node> nodes;
+            SurfaceMaterial->Flatten(nodes);
+            RtwCheck(rtw_scene_set_material(Scene, idx, nodes.data(), (int)nodes.size()));
+        }
+    }
+    // closest hit of one ray; returns the shape index or -1 (Src/RayTracerScene.cpp:99-125)
+    int FindIntersectionWithScene(RRay TestRay, RayHitResult& OutResult)
+    {
+        Commit();
+        const float ray[7] = { TestRay.Origin.x, TestRay.Origin.y, TestRay.Origin.z, TestRay.Direction.x, TestRay.Direction.y, TestRay.Direction.z, TestRay.Distance };
+        float h[11]; int32_t shape = -1, tri = -1;
+        RtwCheck(rtw_trace_closest(Scene, ray, 1, h, &shape, &tri));
+        if (shape >= 0) {
+            OutResult.HitPosition = RVec3(h[0], h[1], h[2]); OutResult.HitNormal = RVec3(h[3], h[4], h[5]); OutResult.Distance = h[6];
+            OutResult.SampledColor = RVec3(h[7], h[8], h[9]); OutResult.SampledAlpha = h[10];
+        }
+        return shape;
+    }
+    // radiance along one ray (Src/RayTracerScene.cpp:31-97); (pixel, sample) select the random stream
+    RVec3 RayTrace(const RRay& InRay, int MaxBounceTimes, const RenderOption& InOption, uint32_t pixel, uint32_t sample, uint32_t seed, int width, int height)
+    {
+        Commit();
+        const float ray[7] = { InRay.Origin.x, InRay.Origin.y, InRay.Origin.z, InRay.Direction.x, InRay.Direction.y, InRay.Direction.z, InRay.Distance };
+        const uint32_t key[2] = { pixel, sample };
+        float rgb[3];
+        RtwCheck(rtw_ray_trace(Scene, ray, key, 1, MaxBounceTimes, InOption.UseBaseColor ? 1 : 0, seed, width, height, rgb));
+        return RVec3(rgb[0], rgb[1], rgb[2]);
+    }
+    void Commit() { if (!Committed) { RtwCheck(rtw_scene_commit(Scene)); Committed = true; } }
+    rtw_scene* Get() { Commit(); return Scene; }
+private:
+    RayTracerScene(const RayTracerScene&); RayTracerScene& operator=(const RayTracerScene&);
+    rtw_scene* Scene; bool Committed;
+};
+
+// ---- Src/RayTracerProgram.cpp:131 ---------------------------------------------------------------------------------------------------
+// One pass over pixels begin..end (inclusive).  PassIndex / Seed pick the random streams (the reference draws from rand()).
+inline void ThreadWorker_Render(RayTracerScene& Scene, ColorBuffer& Buffer, int begin, int end, int MaxBounceCount,
+                                const RenderOption& InOption = RenderOption(), int PassIndex = 0, uint32_t Seed = 12345, int SubSamples = 4)
+{
+    RtwCheck(rtw_render_range(Scene.Get(), Buffer.Get(), begin, end, MaxBounceCount, InOption.UseBaseColor ? 1 : 0, PassIndex, SubSamples, Seed));
+}
+
+// ---- Src/Texture.h ------------------------------------------------------------------------------------------------------------------
+class RTexture {
+public:
+    static bool SaveBufferToPNG(const std::string& Filename, const UINT32* Pixels, int width, int height)
+    {
+        return rtw_png_save_argb(Filename.c_str(), Pixels, width, height) == RTW_OK;
+    }
+};

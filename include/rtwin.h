@@ -85,6 +85,9 @@ int rtw_context_synchronize(rtw_context* ctx);
  * traced as 64-ray packets inside the primary kernel (default).  "path_lanes": lanes per ray in the
  * path kernel, 4 (default) or 1. */
 int rtw_context_set_option(rtw_context* ctx, const char* name, int value);
+/* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's primary, path and resolve
+ * kernels, measured on the context's stream; waits for that pass. */
+int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3]);
 const char* rtw_last_error(void);
 const char* rtw_version(void);
 

@@ -228,6 +228,11 @@ class Context:
     def set_option(self, name, value):
         _check(library().rtw_context_set_option(self.h, name.encode(), int(value)))
 
+    def last_pass_kernel_ms(self):
+        out = (C.c_float * 3)()
+        _check(library().rtw_last_pass_kernel_ms(self.h, out))
+        return [float(v) for v in out]
+
     def stats_enable(self, on=True):
         _check(library().rtw_stats_enable(self.h, int(on)))
 

@@ -24,7 +24,9 @@ size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLa
 struct PipelineTuning {
     int path_lanes;        // lanes per ray in the path kernel: 16, 4 or 1
     int lds_wide_count;    // path_lanes 16: 16-wide nodes of shape 0 staged in LDS (0 = read through L2)
+    int path_variant;      // path_lanes 16: 0 = default geometry, 1..3 = occupancy experiments (see launch_render_pipeline)
     int expected_paths;    // queue length seen by the previous pass on this context, -1 = unknown
+    hipEvent_t* timing;    // null, or 4 events recorded before the primary kernel and after each of the three kernels
 };
 int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream);
 // device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)

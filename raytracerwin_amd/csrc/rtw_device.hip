@@ -1271,8 +1271,8 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
 // One owner per queued path: a quartet (LPR = 4 lanes on one ray) or a single lane (LPR = 1); NT threads per block.
 // With LDSQ the block first stages every quad of shape 0 (breadth-first array) in LDS.  When the primary kernel has
 // already done the camera ray's scene query (p.packets), the path resumes from the stored hit record.
-template <bool STATS, bool LDSQ, int NT, int LPR>
-__global__ __launch_bounds__(NT, (LPR == 16 ? 4 : (NT <= 256 ? 4 : 2))) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
+template <bool STATS, bool LDSQ, int NT, int LPR, int MINW = (LPR == 16 ? 4 : (NT <= 256 ? 4 : 2))>
+__global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
 {
 #ifdef RTW_HOST_EMUL
     (void)sc; (void)pb; (void)p; (void)lds_quad_count;
@@ -1468,6 +1468,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     const int block = 256;
     const int grid = (p.count + block - 1) / block;
     int resolve_blocks = grid < 1024 ? grid : 1024;
+    if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
     if (p.packets) {
         if (stats) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
@@ -1475,7 +1476,24 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         if (stats) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     }
-    if (tune.path_lanes == 16) {
+    if (tune.timing) (void)hipEventRecord(tune.timing[1], stream);
+    if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
+        constexpr int NT = 256;         // experiment: no register cap (2 waves/SIMD), staged tree per 4 waves
+        const int blocks = (owners + NT / 16 - 1) / (NT / 16);
+        const size_t dyn = (size_t)tune.lds_wide_count * 448;
+        if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT, 16, 2>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
+        else hipLaunchKernelGGL((path_kernel<false, true, NT, 16, 2>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
+    } else if (tune.path_lanes == 16 && tune.path_variant == 2) {
+        constexpr int NT = 256;         // experiment: tree through L2, 3 waves/SIMD
+        const int blocks = (owners + NT / 16 - 1) / (NT / 16);
+        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 16, 3>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        else hipLaunchKernelGGL((path_kernel<false, false, NT, 16, 3>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+    } else if (tune.path_lanes == 16 && tune.path_variant == 3) {
+        constexpr int NT = 256;         // experiment: tree through L2, 2 waves/SIMD, no spills
+        const int blocks = (owners + NT / 16 - 1) / (NT / 16);
+        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 16, 2>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+        else hipLaunchKernelGGL((path_kernel<false, false, NT, 16, 2>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
+    } else if (tune.path_lanes == 16) {
         if (tune.lds_wide_count > 0) {
             constexpr int NT = 512;     // two blocks per CU share the staged tree between 16 waves
             int blocks = (owners + NT / 16 - 1) / (NT / 16);
@@ -1506,7 +1524,9 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
         else hipLaunchKernelGGL((path_kernel<false, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
     }
+    if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
     hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    if (tune.timing) (void)hipEventRecord(tune.timing[3], stream);
     return (int)hipGetLastError();
 }
 

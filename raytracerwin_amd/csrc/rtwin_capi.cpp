@@ -73,6 +73,9 @@ struct rtw_context {
     long long counters_shape = -1;      // launch shape (work items, samples) the copy in flight belongs to
     long long known_shape = -1;         // launch shape of known_paths
     int known_paths = -1;               // queue length of the latest pass whose copy has completed
+    int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
+    int kernel_timing = 0;              // 1: record events around the three kernels of each pass
+    hipEvent_t timing_events[4] = { nullptr, nullptr, nullptr, nullptr };
 };
 
 struct rtw_scene {
@@ -165,6 +168,7 @@ int rtw_context_destroy(rtw_context* ctx)
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->counters_event) (void)hipEventDestroy(ctx->counters_event);
+    for (int i = 0; i < 4; i++) if (ctx->timing_events[i]) (void)hipEventDestroy(ctx->timing_events[i]);
     delete ctx;
     return RTW_OK;
 }
@@ -187,12 +191,27 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         return RTW_OK;
     }
     if (std::strcmp(name, "packets") == 0) { ctx->packets = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "path_variant") == 0) { ctx->path_variant = value; return RTW_OK; }
+    if (std::strcmp(name, "kernel_timing") == 0) {
+        if (value && !ctx->timing_events[0]) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ctx->timing_events[i]));
+        ctx->kernel_timing = value ? 1 : 0;
+        return RTW_OK;
+    }
     if (std::strcmp(name, "path_lanes") == 0) {
         if (value != 1 && value != 4 && value != 16) return fail(RTW_ERR_INVALID, "path_lanes must be 1, 4 or 16");
         ctx->path_lanes = value;
         return RTW_OK;
     }
     return fail(RTW_ERR_INVALID, std::string("unknown option ") + name);
+}
+
+int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3])
+{
+    if (!ctx || !out3) return fail(RTW_ERR_INVALID, "null argument");
+    if (!ctx->kernel_timing || !ctx->timing_events[0]) return fail(RTW_ERR_STATE, "kernel_timing is off");
+    HIP_TRY(hipEventSynchronize(ctx->timing_events[3]));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out3[i], ctx->timing_events[i], ctx->timing_events[i + 1]));
+    return RTW_OK;
 }
 
 int rtw_context_synchronize(rtw_context* ctx)
@@ -645,6 +664,8 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
             cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
         }
         tune.expected_paths = (cx->known_shape == shape) ? cx->known_paths : -1;
+        tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
+        tune.path_variant = cx->path_variant;
         p.packets = (scene->ctx->packets != 0 && scene->traversal != 0) ? 1 : 0;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
         if (e == hipSuccess && !cx->counters_pending) {     // one copy in flight at a time; its value is used once it has landed
