@@ -248,7 +248,7 @@ def main():
         ctx.stats_enable(False)
         ctx.set_option("kernel_timing", 1)
         kms = []
-        if args.pipeline == 1:
+        if args.pipeline >= 1:
             for i in range(30):
                 R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, K + i, spp, SEED)
                 if i >= 5:
@@ -299,7 +299,7 @@ def main():
             "rays_per_frame": rays_total / K,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": "render pass = primary_kernel + path_kernel + resolve_kernel (one rtw_render_tasks call)" if args.pipeline == 1 else "render_kernel",
+                         "kernel": "render pass = primary_kernel + path_kernel + resolve_kernel (one rtw_render_tasks call)" if args.pipeline >= 1 else "render_kernel",
                          "kernel_ms": pass_ms,
                          "kernels_ms": dict(zip(("primary_kernel", "path_kernel", "resolve_kernel"), kernel_parts)) if kernel_parts else None,
                          "loop_ms_per_step_hip_events": kernel_ms,

@@ -80,8 +80,9 @@ int rtw_context_destroy(rtw_context* ctx);
 /* run every later launch of this context on the caller's hipStream_t (e.g. torch's) */
 int rtw_context_set_stream(rtw_context* ctx, void* hip_stream);
 int rtw_context_synchronize(rtw_context* ctx);
-/* tuning switches; results never depend on them.  "pipeline": 1 = primary / path / resolve
- * launches (default), 0 = single kernel with one thread per pixel.  "packets": 1 = camera rays are
+/* tuning switches; results never depend on them.  "pipeline": 2 = primary / one shade + one trace
+ * launch per bounce / resolve, 1 = primary / path / resolve launches, 0 = single kernel with one
+ * thread per pixel.  "packets": 1 = camera rays are
  * traced as 64-ray packets inside the primary kernel (default).  "path_lanes": lanes per ray in the
  * path kernel, 4 (default) or 1. */
 int rtw_context_set_option(rtw_context* ctx, const char* name, int value);

@@ -15,17 +15,21 @@ inline size_t level_workspace_bytes(long long work_items, int max_bounce)
     const size_t threads = (size_t)((work_items + 255) / 256) * 256;
     return threads * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
 }
-struct PipelineLayout { size_t queue_off, pend_off, counters_off, rad_off, hit_off, ws_off, total; int path_quartets; };
+struct PipelineLayout {
+    size_t queue_off, pend_off, counters_off, rad_off, hit_off, ws_off, total; int path_quartets;
+    size_t wf_capacity, wf_state_off, wf_tlist0_off, wf_tlist1_off, wf_ws_off, wf_total;
+};
 #define RTW_MAX_PATH_QUARTETS (1 << 20)   // quartets (paths in flight) of one path_kernel launch; more paths loop
 #define RTW_PATH_BLOCK_LDS 512            // threads per block when the quads are staged in LDS
 // workspace of the compacted pipeline for a launch of `work_items` pixels (device bytes)
-size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out);
+size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out);   // out->wf_total when the wavefront pipeline is used
 // lds_quad_count: how many of shape 0's quads (breadth-first order) each path_kernel block stages in LDS
 struct PipelineTuning {
     int path_lanes;        // lanes per ray in the path kernel: 16, 4 or 1
     int lds_wide_count;    // path_lanes 16: 16-wide nodes of shape 0 staged in LDS (0 = read through L2)
     int path_variant;      // path_lanes 16: 0 = default geometry, 1..3 = occupancy experiments (see launch_render_pipeline)
     int expected_paths;    // queue length seen by the previous pass on this context, -1 = unknown
+    int round_hint[32];    // wavefront: trace-list lengths of the previous pass per round, -1 = unknown
     hipEvent_t* timing;    // null, or 4 events recorded before the primary kernel and after each of the three kernels
 };
 int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream);

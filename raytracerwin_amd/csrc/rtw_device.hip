@@ -11,6 +11,8 @@
 #endif
 #include <float.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "rtw_types.h"
 #ifndef RTW_HOST_EMUL
@@ -1159,9 +1161,36 @@ struct PipeBufs {
     uint32_t* __restrict__ pend;       // work items with at least one queued sample
     float4* __restrict__ rad;          // radiance per path id (only slots of pending pixels are used)
     float4* __restrict__ hitrec;       // with primary packets: 2 x float4 per path id (position + distance, shape + leaf slot)
-    uint32_t* __restrict__ counters;   // [0] queue length, [1] pending length
-    float4* __restrict__ ws;           // level store of path_kernel's threads
+    uint32_t* __restrict__ counters;   // [0] queue length, [1] pending length, [4 + r] length of round r's trace list
+    float4* __restrict__ ws;           // level store of path_kernel's threads / of the wavefront pipeline's path slots
+    // wavefront pipeline (one launch per bounce): everything below is indexed by the dense path slot = queue index
+    float4* __restrict__ hitslot;      // 2 x float4 per slot: hit position + distance, shape + leaf slot
+    float4* __restrict__ state;        // 3 x float4 per slot: origin + distance, direction + draw counter, key / table reads / levels / depth
+    uint32_t* __restrict__ tlist0;     // trace lists (slots whose next segment must be traced), ping-pong
+    uint32_t* __restrict__ tlist1;
+    uint32_t capacity;                 // slots the dense arrays hold
 };
+
+// like wave_push, returns the index the value was stored at (or 0xFFFFFFFF)
+__device__ __forceinline__ uint32_t wave_push_slot(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
+{
+#ifdef RTW_HOST_EMUL
+    if (!flag) return 0xFFFFFFFFu;
+    list[*counter] = value; return (*counter)++;
+#else
+    const unsigned long long m = __ballot(flag);
+    if (m == 0ull) return 0xFFFFFFFFu;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (!flag) return 0xFFFFFFFFu;
+    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    list[at] = value;
+    return at;
+#endif
+}
 
 __device__ __forceinline__ void wave_push(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
 {
@@ -1200,6 +1229,8 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
     const bool live = pixel < npix;
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     f3 s[4];
+    float4 hr0[4], hr1[4];
+    for (int i = 0; i < 4; i++) { hr0[i] = make_float4(0.f, 0.f, 0.f, 0.f); hr1[i] = hr0[i]; }
     uint32_t queued = 0, full_trace = 0;
     const uint32_t phase = table_phase(p.seed);
     const int n_shapes = sc->n_shapes;
@@ -1248,8 +1279,13 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
         }
         if (hit_shape < 0) { s[i] = sky_color(ray.d.y); continue; }
         queued |= 1u << i;
-        pb.hitrec[((size_t)wi * 4 + i) * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
-        pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
+        if (p.wavefront) {      // the record goes to the path's dense slot, known once the sample has been queued (below)
+            hr0[i] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
+            hr1[i] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
+        } else {
+            pb.hitrec[((size_t)wi * 4 + i) * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
+            pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
+        }
     }
     if (live) {
         if (queued == 0) {
@@ -1263,7 +1299,10 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
         }
     }
     // bit 31 of a queue entry: no hit record, trace the path from the camera ray
-    for (int i = 0; i < 4; i++) wave_push(pb.queue, &pb.counters[0], (queued >> i) & 1u, ((uint32_t)wi * 4u + (uint32_t)i) | (((full_trace >> i) & 1u) << 31));
+    for (int i = 0; i < 4; i++) {
+        const uint32_t at = wave_push_slot(pb.queue, &pb.counters[0], (queued >> i) & 1u, ((uint32_t)wi * 4u + (uint32_t)i) | (((full_trace >> i) & 1u) << 31));
+        if (PACKET && p.wavefront && at != 0xFFFFFFFFu && at < pb.capacity) { pb.hitslot[(size_t)at * 2] = hr0[i]; pb.hitslot[(size_t)at * 2 + 1] = hr1[i]; }
+    }
     wave_push(pb.pend, &pb.counters[1], queued != 0, (uint32_t)wi);
     if (STATS) flush_counters(sc, ct);
 }
@@ -1333,6 +1372,166 @@ __global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __res
     if (STATS) flush_counters(sc, ct);
 #endif
 }
+
+// ======================================================================================================
+// Wavefront pipeline: one launch per bounce instead of one kernel that carries every path to its end.
+//   shade_kernel  ONE lane per path (the shading step is a chain of dependent loads, not arithmetic): shading
+//                 inputs of the recorded hit, material bounce, alpha test, level push; a path that continues
+//                 saves its ray and joins the next trace list, a path that ends folds its levels and writes
+//                 its radiance.  Round 0 regenerates the camera ray of each queued sample.
+//   trace_kernel  SIXTEEN lanes per ray: FindIntersectionWithScene of the saved ray on the 16-wide tree, result
+//                 written as a hit record.  Only the rays that are still alive are launched (dense lists).
+// Every float operation is the one the single-kernel forms execute, in the same order.
+// ======================================================================================================
+__device__ __forceinline__ const uint32_t* wf_list(const PipeBufs& pb, int which) { return which ? pb.tlist1 : pb.tlist0; }
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
+{
+    const uint32_t n = round == 0 ? pb.counters[0] : pb.counters[4 + round - 1];
+    const uint32_t* __restrict__ src = round == 0 ? nullptr : wf_list(pb, (round - 1) & 1);
+    uint32_t* __restrict__ dst = round & 1 ? pb.tlist1 : pb.tlist0;
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    const int npix = p.width * p.height;
+    const uint32_t phase = table_phase(p.seed);
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
+    const uint32_t rounds_of_wave = (n + nthreads - 1) / nthreads;       // wave-uniform trip count: every lane joins the pushes
+    for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < rounds_of_wave; it++, k += nthreads) {
+        const bool live = k < n;
+        const uint32_t q = live ? (round == 0 ? k : src[k]) : 0u;
+        bool go_on = false;                                                // this path has another segment to trace
+        if (live && q < pb.capacity) {
+            const uint32_t qe = pb.queue[q];
+            const uint32_t pid = qe & 0x7FFFFFFFu;
+            const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
+            const int pixel = work_to_pixel(p, wi);
+            PathRng rng; Ray ray; int depth, nlev;
+            bool have_hit = true;
+            if (round == 0) {
+                rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
+                ray = camera_ray(p.width, p.height, pixel, sub, rng);
+                depth = p.max_bounce; nlev = 0;
+                if (qe >> 31) have_hit = false;                            // untame camera ray: its first segment is traced like any other
+            } else {
+                const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1], s2 = pb.state[(size_t)q * 3 + 2];
+                ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+                rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
+                rng.table_base = (((uint64_t)p.pass_index * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
+                nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
+            }
+            LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
+            f3 L = mk(0, 0, 0);
+            bool done = false;
+            if (have_hit) {
+                const float4 r0 = pb.hitslot[(size_t)q * 2], r1 = pb.hitslot[(size_t)q * 2 + 1];
+                const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
+                if (hs < 0) { L = sky_color(ray.d.y); done = true; }
+                else {
+                    const RtwShapeDev& sh = sc->shapes[hs];
+                    Hit h; int tri_index;
+                    mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+                    if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
+                    else {
+                        Ray out = ray;
+                        if (p.preview) {
+                            const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
+                            L = mk(0, 0, 0) + pv.att * h.color; done = true;
+                        } else {
+                            const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
+                            if (rng.random() <= h.alpha) {
+                                if (all_nonzero(b.att)) {
+                                    lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
+                                    lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                                    lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+                                    nlev++;
+                                    ray = out;
+                                } else { L = mk(0, 0, 0) + b.em; done = true; }
+                            } else {
+                                lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+                                nlev++;
+                                const float rd = ray.dist - h.dist;
+                                ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
+                            }
+                            if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
+                        }
+                    }
+                }
+            }
+            if (done) {
+                for (int kk = nlev - 1; kk >= 0; kk--) {
+                    const float4 a = lv.at(kk, 0);
+                    if (__float_as_int(a.w) == 0) {
+                        const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
+                        L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
+                    } else {
+                        L = mk(0, 0, 0) + L;
+                    }
+                }
+                pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+            } else {
+                pb.state[(size_t)q * 3] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
+                pb.state[(size_t)q * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
+                pb.state[(size_t)q * 3 + 2] = make_float4(__uint_as_float(rng.key), __uint_as_float(rng.table_reads),
+                                                          __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
+                go_on = true;
+            }
+        }
+        wave_push(dst, &pb.counters[4 + round], go_on, q);
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+#ifndef RTW_HOST_EMUL
+template <bool STATS>
+__global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
+{
+    __shared__ uint32_t trav_words[(RTW_WIDE_STACK + RTW_WIDE_CAND) * 16];
+    const uint32_t n = pb.counters[4 + round];
+    if (blockIdx.x * 16u >= n) return;
+    const uint32_t* __restrict__ src = wf_list(pb, round & 1);
+    const TravCtx tc = make_trav16(trav_words, 256, nullptr);
+    const uint32_t ngroups = gridDim.x * 16u;
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    const bool prune = sc->prune != 0;
+    for (uint32_t k = blockIdx.x * 16u + (threadIdx.x >> 4); k < n; k += ngroups) {
+        const uint32_t q = src[k];
+        const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1];
+        Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+        // FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) without the shading tail: only the record of
+        // the last shape that hit is ever read, and a shape's tail does not influence the next shape's query
+        int hit_shape = -1, hit_slot = -1;
+        f3 hit_pos = mk(0, 0, 0);
+        float seg = ray.dist;
+        if (STATS && tc.count) ct.rays++;
+        const bool tame = ray_is_tame(ray);
+        for (int s = 0; s < sc->n_shapes; s++) {
+            const RtwShapeDev& sh = sc->shapes[s];
+            float t0, t1;
+            if (STATS && tc.count) ct.boxes++;
+            if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+            float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
+            bool any;
+            Counters walk = { 0, 0, 0, 0, 0, 0 };
+            if (sh.n_wides > 0 && sc->traversal != 0) {
+                if (tame) any = wide_walk16<STATS, false, false>(sh, tc, ray, prune, cur, pos, slot, walk);
+                else any = wide_walk16<STATS, false, true>(sh, tc, ray, false, cur, pos, slot, walk);
+                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
+            } else {
+                if (tame) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, prune, cur, pos, slot, walk);
+                else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, false, cur, pos, slot, walk);
+                if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
+            }
+            if (any) { seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos; }
+        }
+        if (tc.lane4 == 0) {
+            pb.hitslot[(size_t)q * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
+            pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
+        }
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+#endif
 
 __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
                                                       uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
@@ -1435,6 +1634,13 @@ size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLa
     l.hit_off = l.rad_off + up(n * 4 * 16);
     l.ws_off = l.hit_off + up(n * 4 * 32);
     l.total = l.ws_off + ((size_t)l.path_quartets + 256) * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
+    // wavefront pipeline: dense per-slot arrays for every possible path (n * 4), level store included
+    l.wf_capacity = n * 4;
+    l.wf_state_off = up(l.total);
+    l.wf_tlist0_off = l.wf_state_off + up(l.wf_capacity * 48);
+    l.wf_tlist1_off = l.wf_tlist0_off + up(l.wf_capacity * 4);
+    l.wf_ws_off = l.wf_tlist1_off + up(l.wf_capacity * 4);
+    l.wf_total = l.wf_ws_off + l.wf_capacity * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
     if (out) *out = l;
     return l.total;
 }
@@ -1455,8 +1661,14 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     PipeBufs pb;
     pb.queue = (uint32_t*)(w + l.queue_off); pb.pend = (uint32_t*)(w + l.pend_off); pb.counters = (uint32_t*)(w + l.counters_off);
     pb.rad = (float4*)(w + l.rad_off); pb.hitrec = (float4*)(w + l.hit_off); pb.ws = (float4*)(w + l.ws_off);
-    hipError_t e = hipMemsetAsync(pb.counters, 0, 16, stream);
+    hipError_t e = hipMemsetAsync(pb.counters, 0, 256, stream);
     if (e != hipSuccess) return (int)e;
+    if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "memset -> %s (wavefront %d packets %d)\n", hipGetErrorString(hipPeekAtLastError()), p.wavefront, p.packets);
+    pb.hitslot = pb.hitrec; pb.state = nullptr; pb.tlist0 = pb.tlist1 = nullptr; pb.capacity = 0;
+    if (p.wavefront) {
+        pb.state = (float4*)(w + l.wf_state_off); pb.tlist0 = (uint32_t*)(w + l.wf_tlist0_off); pb.tlist1 = (uint32_t*)(w + l.wf_tlist1_off);
+        pb.ws = (float4*)(w + l.wf_ws_off); pb.capacity = (uint32_t)l.wf_capacity;
+    }
     // Path owners (quartets / groups / lanes) to launch.  The true queue length is only known on the device;
     // the host passes the length the previous pass had (frames of a progressive render barely differ) plus a
     // margin.  Any shortfall is absorbed by the owners' stride loop, any excess by blocks that exit at once.
@@ -1476,8 +1688,32 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         if (stats) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     }
+    if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "primary -> %s\n", hipGetErrorString(hipPeekAtLastError()));
     if (tune.timing) (void)hipEventRecord(tune.timing[1], stream);
-    if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
+    if (p.wavefront) {
+        // shade(0), then trace(r) / shade(r + 1): a path queued with a hit record ends at the latest in shade(max_bounce - 1),
+        // one whose camera ray still has to be traced in shade(max_bounce)
+        auto size_for = [&](int round, int lanes_per_item) {
+            long long items = round == 0 ? owners : (tune.round_hint[round - 1] >= 0 ? (long long)tune.round_hint[round - 1] + tune.round_hint[round - 1] / 4 + 256 : owners);
+            if (items > owners) items = owners;
+            long long blocks = (items * lanes_per_item + 255) / 256;
+            if (blocks < 1) blocks = 1;
+            if (blocks > 262144) blocks = 262144;
+            return (int)blocks;
+        };
+        for (int r = 0; r <= p.max_bounce; r++) {
+            if (r > 0) {
+                const int tb = size_for(r, 16);
+                if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
+                else hipLaunchKernelGGL(trace_kernel<false>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
+                if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "trace round %d blocks %d -> %s\n", r - 1, tb, hipGetErrorString(hipPeekAtLastError()));
+            }
+            const int sb = size_for(r, 1);
+            if (stats) hipLaunchKernelGGL(shade_kernel<true>, dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
+            else hipLaunchKernelGGL(shade_kernel<false>, dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
+            if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "shade round %d blocks %d -> %s\n", r, sb, hipGetErrorString(hipPeekAtLastError()));
+        }
+    } else if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
         constexpr int NT = 256;         // experiment: no register cap (2 waves/SIMD), staged tree per 4 waves
         const int blocks = (owners + NT / 16 - 1) / (NT / 16);
         const size_t dyn = (size_t)tune.lds_wide_count * 448;

@@ -107,6 +107,7 @@ struct RtwRenderParams {
     int32_t max_bounce, preview, pass_index, sub_samples;
     uint32_t seed;
     int32_t packets;                // 1: the primary kernel does the camera rays' scene query as packet walks
+    int32_t wavefront;              // 1: one shade + one trace launch per bounce instead of the all-in-one path kernel
 };
 
 // random-stream constants (shared with the oracle by specification, not by code)

@@ -73,6 +73,7 @@ struct rtw_context {
     long long counters_shape = -1;      // launch shape (work items, samples) the copy in flight belongs to
     long long known_shape = -1;         // launch shape of known_paths
     int known_paths = -1;               // queue length of the latest pass whose copy has completed
+    int known_rounds[32];               // wavefront: trace-list lengths of that pass
     int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
     int kernel_timing = 0;              // 1: record events around the three kernels of each pass
     hipEvent_t timing_events[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -150,9 +151,10 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipMalloc((void**)&c->d_lut, sizeof lut));
     HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
-    HIP_TRY(hipHostMalloc((void**)&c->h_counters, 16, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&c->counters_event, hipEventDisableTiming));
-    c->h_counters[0] = c->h_counters[1] = c->h_counters[2] = c->h_counters[3] = 0;
+    for (int i = 0; i < 64; i++) c->h_counters[i] = 0;
+    for (int r = 0; r < 32; r++) c->known_rounds[r] = -1;
     HIP_TRY(hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)));
     *out = c.release();
@@ -186,7 +188,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
 {
     if (!ctx || !name) return fail(RTW_ERR_INVALID, "null argument");
     if (std::strcmp(name, "pipeline") == 0) {
-        if (value != 0 && value != 1) return fail(RTW_ERR_INVALID, "pipeline must be 0 or 1");
+        if (value < 0 || value > 2) return fail(RTW_ERR_INVALID, "pipeline must be 0, 1 or 2");
         ctx->pipeline = value;
         return RTW_OK;
     }
@@ -642,7 +644,9 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
     hipError_t e;
     if (scene->ctx->pipeline >= 1) {
-        int rc = ensure_workspace(scene->ctx, rtw::pipeline_workspace_bytes(p.count, max_bounce, nullptr)); if (rc != RTW_OK) return rc;
+        rtw::PipelineLayout layout;
+        rtw::pipeline_workspace_bytes(p.count, max_bounce, &layout);
+        int rc = ensure_workspace(scene->ctx, scene->ctx->pipeline == 2 ? layout.wf_total : layout.total); if (rc != RTW_OK) return rc;
         int lds_quads = 0;
         if (scene->ctx->path_lanes == 4 && scene->traversal != 0 && !scene->meshes.empty() && scene->meshes[0]->quad_depth <= RTW_QUAD_STACK) {
             lds_quads = (int)scene->meshes[0]->quads.size();
@@ -662,15 +666,18 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         const long long shape = (long long)p.count * 64 + sub_samples;
         if (cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
             cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
+            for (int r = 0; r < 32; r++) cx->known_rounds[r] = (int)cx->h_counters[4 + r];
         }
         tune.expected_paths = (cx->known_shape == shape) ? cx->known_paths : -1;
+        for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
+        p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
+        p.wavefront = (cx->pipeline == 2 && p.packets) ? 1 : 0;
         tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
         tune.path_variant = cx->path_variant;
-        p.packets = (scene->ctx->packets != 0 && scene->traversal != 0) ? 1 : 0;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
         if (e == hipSuccess && !cx->counters_pending) {     // one copy in flight at a time; its value is used once it has landed
             const size_t off = rtw::pipeline_counters_offset(p.count, max_bounce);
-            if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + off, 16, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
+            if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + off, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
                 hipEventRecord(cx->counters_event, cx->stream) == hipSuccess) {
                 cx->counters_pending = true; cx->counters_shape = shape;
             }

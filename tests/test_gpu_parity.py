@@ -303,7 +303,7 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     W, H = 1280, 720
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
     out = []
-    for mode, packets, lanes in ((0, 0, 4), (1, 0, 4), (1, 0, 1), (1, 1, 4), (1, 1, 1), (1, 0, 16), (1, 1, 16)):
+    for mode, packets, lanes in ((0, 0, 4), (1, 0, 4), (1, 0, 1), (1, 1, 4), (1, 1, 1), (1, 0, 16), (1, 1, 16), (2, 1, 16)):
         ctx.set_option("pipeline", mode)
         ctx.set_option("packets", packets)
         ctx.set_option("path_lanes", lanes)
