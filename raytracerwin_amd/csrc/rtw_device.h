@@ -30,6 +30,10 @@ struct PipelineTuning {
     int path_variant;      // path_lanes 16: 0 = default geometry, 1..3 = occupancy experiments (see launch_render_pipeline)
     int expected_paths;    // queue length seen by the previous pass on this context, -1 = unknown
     int round_hint[32];    // wavefront: trace-list lengths of the previous pass per round, -1 = unknown
+    int wave_stage;        // bins + wave pipeline: what pathwave_kernel's blocks stage in LDS for shape 0 (0 nothing .. 3 levels + triangles)
+    size_t wave_stage_bytes;   // bytes of those arrays
+    int wave_fused;        // 1: pathwave_kernel carries the paths to their end, 0: one shade + one wave-per-ray trace launch per bounce
+    int wave_blocks;       // staged variants: blocks to launch at most (one per CU)
     hipEvent_t* timing;    // null, or 4 events recorded before the primary kernel and after each of the three kernels
 };
 int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream);

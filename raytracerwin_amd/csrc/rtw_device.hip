@@ -101,18 +101,24 @@ typedef __attribute__((address_space(3))) const float rtw_l_f1;
 typedef __attribute__((address_space(3))) const uint32_t rtw_l_u1;
 typedef __attribute__((address_space(3))) uint32_t rtw_l_u1w;
 typedef __attribute__((address_space(4))) const float4 rtw_c_f4;
+typedef __attribute__((address_space(4))) const uint32_t rtw_c_u1;
+__device__ __forceinline__ uint32_t cldu(const uint32_t* p, int i) { return ((rtw_c_u1*)p)[i]; }
 // wave-uniform address in read-only memory: becomes an s_load (scalar cache), no vector memory instruction
 __device__ __forceinline__ float4 cld4(const float4* p, int i) { return ((rtw_c_f4*)p)[i]; }
 __device__ __forceinline__ float4 gld4(const float4* p, size_t i) { return ((rtw_g_f4*)p)[i]; }
 __device__ __forceinline__ float gld1(const float* p, size_t i) { return ((rtw_g_f1*)p)[i]; }
 __device__ __forceinline__ float lld1(const float* p, int i) { return ((rtw_l_f1*)p)[i]; }
+typedef __attribute__((address_space(3))) const float4 rtw_l_f4;
+__device__ __forceinline__ float4 lld4(const float4* p, int i) { return ((rtw_l_f4*)p)[i]; }
 __device__ __forceinline__ uint32_t lldu(const uint32_t* p, int i) { return ((rtw_l_u1*)p)[i]; }
 __device__ __forceinline__ void lstu(uint32_t* p, int i, uint32_t v) { ((rtw_l_u1w*)p)[i] = v; }
 #else
 __device__ __forceinline__ float4 cld4(const float4* p, int i) { return p[i]; }
+__device__ __forceinline__ uint32_t cldu(const uint32_t* p, int i) { return p[i]; }
 __device__ __forceinline__ float4 gld4(const float4* p, size_t i) { return p[i]; }
 __device__ __forceinline__ float gld1(const float* p, size_t i) { return p[i]; }
 __device__ __forceinline__ float lld1(const float* p, int i) { return p[i]; }
+__device__ __forceinline__ float4 lld4(const float4* p, int i) { return p[i]; }
 __device__ __forceinline__ uint32_t lldu(const uint32_t* p, int i) { return p[i]; }
 __device__ __forceinline__ void lstu(uint32_t* p, int i, uint32_t v) { p[i] = v; }
 #endif
@@ -1110,6 +1116,19 @@ __device__ __forceinline__ void resolve_pixel(const float* __restrict__ thr, flo
 
 __device__ __forceinline__ int work_to_pixel(const RtwRenderParams& p, int wi)
 {
+    if (p.tile_w != 0) {            // wave (wi >> 6) renders one tile_w x tile_h tile; lanes row-major inside the tile
+        const int wt = wi >> 6, l = wi & 63;
+        int band = (int)(((float)wt + 0.5f) / (float)p.tiles_per_row);
+        if (band * p.tiles_per_row > wt) band--;
+        if ((band + 1) * p.tiles_per_row <= wt) band++;
+        const int tx = wt - band * p.tiles_per_row;
+        const int vr = band * p.tile_h + (l >> p.tile_shift);
+        const int x = tx * p.tile_w + (l & (p.tile_w - 1));
+        int y;
+        if (p.world <= 1) y = p.row0 + vr;
+        else { const int j = vr / p.task_rows, r = vr - j * p.task_rows; y = (j * p.world + p.rank) * p.task_rows + r; }
+        return (vr < p.nrows && y < p.height) ? y * p.width + x : p.width * p.height;
+    }
     if (p.world <= 1) return p.begin + wi;
     const int per_task = p.task_rows * p.width;
     const int j = wi / per_task, r = wi - j * per_task;
@@ -1533,6 +1552,10 @@ __global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restric
 }
 #endif
 
+#ifndef RTW_HOST_EMUL
+#include "rtw_wave_kernels.h"
+#endif
+
 __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
                                                       uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
 {
@@ -1681,7 +1704,10 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     const int grid = (p.count + block - 1) / block;
     int resolve_blocks = grid < 1024 ? grid : 1024;
     if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
-    if (p.packets) {
+    if (p.wavefront == 2) {
+        if (stats) hipLaunchKernelGGL(primary_bins_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        else hipLaunchKernelGGL(primary_bins_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    } else if (p.packets) {
         if (stats) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     } else {
@@ -1690,7 +1716,65 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     }
     if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "primary -> %s\n", hipGetErrorString(hipPeekAtLastError()));
     if (tune.timing) (void)hipEventRecord(tune.timing[1], stream);
-    if (p.wavefront) {
+    if (p.wavefront == 2 && !tune.wave_fused) {
+        // shade(0), then trace(r) / shade(r + 1) for r = 0 .. max_bounce - 2: every queued path has a hit record, the last shade
+        // step sees depth 0.  Trace rounds: a wave per ray, persistent blocks (one per CU when shape 0 is staged in LDS).
+        auto items_of = [&](int round) {
+            long long items = round == 0 ? owners : (tune.round_hint[round - 1] >= 0 ? (long long)tune.round_hint[round - 1] + tune.round_hint[round - 1] / 4 + 256 : owners);
+            return items > owners ? (long long)owners : items;
+        };
+        for (int r = 0; r < p.max_bounce; r++) {
+            if (r > 0) {
+                const long long rays = items_of(r);
+                const int stage = tune.wave_stage;
+#define RTW_LAUNCH_TW(ST, NTV)                                                                                                                  \
+                do {                                                                                                                            \
+                    long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);                                                                      \
+                    if (blocks < 1) blocks = 1;                                                                                                 \
+                    if (blocks > (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? 8 : 1)) blocks = (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? 8 : 1); \
+                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4 + (ST == 0 ? 0 : tune.wave_stage_bytes);                     \
+                    if (stats) { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<true, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                        hipLaunchKernelGGL((trace_wave_kernel<true, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
+                    else { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<false, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                        hipLaunchKernelGGL((trace_wave_kernel<false, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
+                } while (0)
+                if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
+#undef RTW_LAUNCH_TW
+            }
+            long long sb = (items_of(r) + 255) / 256;
+            if (sb < 1) sb = 1;
+            if (sb > 262144) sb = 262144;
+            if (stats) hipLaunchKernelGGL(shade_kernel<true>, dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+            else hipLaunchKernelGGL(shade_kernel<false>, dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+        }
+    } else if (p.wavefront == 2) {
+        // one wave per p.wave_paths queued paths; blocks past the real queue leave at once
+        long long waves = ((long long)owners + p.wave_paths - 1) / p.wave_paths;
+        const int stage = tune.wave_stage;
+        if (stage > 0) {
+            constexpr int NT = 1024;        // one block per CU: its 16 waves share the staged arrays
+            long long blocks = (waves + NT / 64 - 1) / (NT / 64);
+            if (blocks < 1) blocks = 1;
+            if (blocks > tune.wave_blocks) blocks = tune.wave_blocks;
+            const size_t dyn = (size_t)(NT / 64) * RTW_WAVE_LDS_WORDS * 4 + tune.wave_stage_bytes;
+#define RTW_LAUNCH_PW(ST)                                                                                                                \
+            do {                                                                                                                         \
+                if (stats) { (void)hipFuncSetAttribute((const void*)pathwave_kernel<true, ST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                    hipLaunchKernelGGL((pathwave_kernel<true, ST, NT>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }     \
+                else { (void)hipFuncSetAttribute((const void*)pathwave_kernel<false, ST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                    hipLaunchKernelGGL((pathwave_kernel<false, ST, NT>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }    \
+            } while (0)
+            if (stage == 1) RTW_LAUNCH_PW(1); else if (stage == 2) RTW_LAUNCH_PW(2); else RTW_LAUNCH_PW(3);
+#undef RTW_LAUNCH_PW
+        } else {
+            long long blocks = (waves + 3) / 4;
+            if (blocks < 1) blocks = 1;
+            if (blocks > 262144) blocks = 262144;
+            const size_t dyn = 4 * RTW_WAVE_LDS_WORDS * 4;
+            if (stats) hipLaunchKernelGGL((pathwave_kernel<true, 0, 256>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
+            else hipLaunchKernelGGL((pathwave_kernel<false, 0, 256>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
+        }
+    } else if (p.wavefront) {
         // shade(0), then trace(r) / shade(r + 1): a path queued with a hit record ends at the latest in shade(max_bounce - 1),
         // one whose camera ray still has to be traced in shade(max_bounce)
         auto size_for = [&](int round, int lanes_per_item) {

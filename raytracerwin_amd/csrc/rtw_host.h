@@ -36,6 +36,8 @@ struct HostMesh {
     std::vector<RtwWide> wides;        // 16-wide collapse, BFS order
     int wide_depth = 0;
     int max_depth = 0;
+    std::vector<float> flat[3];        // flat hierarchy over the leaves in preorder, see RtwShapeDev::flat
+    int flat_n[3] = { 0, 0, 0 }, flat_pad[3] = { 0, 0, 0 };
     int n_tris() const { return (int)(point_idx.size() / 3); }
 };
 
@@ -48,6 +50,13 @@ std::string finish_arrays(HostMesh& m, const float* bounds6);
 void build_tree(HostMesh& m);
 // 4-wide collapse of m.nodes (slot order = preorder), numbered breadth-first.
 void build_quads(HostMesh& m);
+// Flat hierarchy: leaf boxes in preorder and the unions of every 16 / 256 consecutive leaves (needs build_tree()).
+void build_flat(HostMesh& m);
+// Screen-space bins of the reference camera (Src/RayTracerProgram.cpp:133-165: origin (0,0,7), image plane z = -0.5)
+// for a width x height frame cut into bin_w x bin_h pixel bins: for each bin the leaves (node indices, ascending) whose
+// box the line of any camera ray of the bin's pixels can meet.  Returns false (no bins) when some leaf box is not
+// wholly in front of the camera.
+bool build_bins(const HostMesh& m, int width, int height, int bin_w, int bin_h, std::vector<uint32_t>& off, std::vector<uint32_t>& ent);
 
 // tables
 uint32_t rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);

@@ -77,6 +77,12 @@ struct RtwShapeDev {
     const RtwQuad* quads;           // BFS order; null / n_quads == 0 -> binary walk only
     const RtwWide* wides;           // BFS order; null / n_wides == 0 -> no 16-lane walk
     int32_t n_wides, wide_depth;
+    // flat hierarchy over the leaves in preorder (16 consecutive entries of a level share one entry of the next):
+    // level 0 = the leaves' own boxes, 1 = groups of 16 leaves, 2 = groups of 256.  Each level is six float arrays
+    // (min x/y/z, max x/y/z) of flat_pad[l] entries, component c of entry i at flat[l][c * flat_pad[l] + i].
+    const float* flat[3];
+    int32_t flat_n[3], flat_pad[3];
+    int32_t pad_flat0, pad_flat1;
     float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
     int32_t n_quads, quad_depth;
     int32_t n_nodes, n_tris;
@@ -108,6 +114,19 @@ struct RtwRenderParams {
     uint32_t seed;
     int32_t packets;                // 1: the primary kernel does the camera rays' scene query as packet walks
     int32_t wavefront;              // 1: one shade + one trace launch per bounce instead of the all-in-one path kernel
+    // tiled work mapping (tile_w != 0): wave w of the launch renders the tile_w x tile_h pixel tile number w of its rows,
+    // aligned to the screen's bin grid; `bins` then holds, per shape, the leaves whose box can be met by a camera ray of each bin
+    int32_t tile_w, tile_h, tile_shift, tiles_per_row;
+    int32_t row0, nrows;            // contiguous range: first screen row and number of rows; task partition: number of virtual rows
+    int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
+    int32_t pad_params;
+    const struct RtwBinsDev* bins;  // [n_shapes] or null
+};
+
+// screen-space bins of one shape for one (width, height, tile shape): CSR over the bins, entries = node index of a leaf, ascending
+struct RtwBinsDev {
+    const uint32_t* off;            // n_bins + 1 offsets, or null: no bins for this shape (camera too close to it) -> tree walk
+    const uint32_t* ent;
 };
 
 // random-stream constants (shared with the oracle by specification, not by code)

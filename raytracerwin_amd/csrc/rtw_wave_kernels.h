@@ -1,0 +1,524 @@
+// rtw_wave_kernels.h -- the "bins + wave" pipeline (pipeline 3).  Included inside rtw_device.hip's anonymous
+// namespace (device build only); it uses that file's ray / triangle / shading helpers unchanged.
+//
+//   primary_bins_kernel  one thread per pixel, one wave per screen tile.  The camera is the reference's fixed one
+//                        (Src/RayTracerProgram.cpp:133-165), so the leaves a tile's camera rays can meet are known
+//                        before the frame starts (RtwBinsDev, built on the host): the wave runs through that short
+//                        list -- wave-uniform index, records through scalar loads, nothing pointer-chased -- and each
+//                        lane gives its own ray the reference's box test and triangle test, in preorder, with its
+//                        own shrinking segment.  Misses are finished here, hits are queued with their hit record.
+//   pathwave_kernel      a wave owns `wave_paths` queued paths, one per lane, and carries them to their end: the
+//                        shading step runs lane-parallel (one path per lane), every secondary segment is then traced
+//                        by the WHOLE wave, one ray at a time: 64 lanes test 64 boxes of the flat hierarchy per step
+//                        (no stack, wave-uniform control flow, no divergence), candidate leaves come out in preorder
+//                        and are triangle-tested 64 at a time with the reference's shrinking segment.  No relaunch
+//                        per bounce, no inter-wave traffic.
+//
+// Why the results are the reference's bits: KdNode::TestRayIntersection (Src/KdTree.cpp:128-195) tests exactly the
+// leaves whose own box the ray's line meets, in preorder, each with the segment left by the previous accepted hit.
+// Both kernels meet a superset-filtered list of leaves in preorder, apply the reference's own box test to the leaf's
+// own box and the reference's triangle test with the running segment; every float operation is the one the other
+// pipelines execute (same helpers).
+
+#define RTW_WAVE_LDS_WORDS 256      // per wave: 64 level-2 hits, 64 level-1 hits, 128 candidate leaves
+#ifndef RTW_PATHWAVE_MINW
+#define RTW_PATHWAVE_MINW 4
+#endif
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int mbcnt(unsigned long long m)      // set bits of m below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// LDS words written by some lanes of the wave are read by others: nothing to wait for in hardware (a wave's LDS
+// operations execute in order), the fences only keep the compiler from moving the accesses across each other
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct FlatRay { f3 o; float ix, iy, iz, eps_t; };
+
+// reference box test of a tame ray (RRay::TestIntersectionWithAabb, Src/RRay.cpp:89-136) on entry idx of a flat
+// level, plus the conservative segment clip when `prune`
+// LDSB: the level's arrays were staged in LDS by the block (same layout)
+template <bool LDSB>
+__device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pad, int idx, const FlatRay& fr, bool prune, float far_t)
+{
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    if (LDSB) {
+        mnx = lld1(b, idx); mny = lld1(b, pad + idx); mnz = lld1(b, 2 * pad + idx);
+        mxx = lld1(b, 3 * pad + idx); mxy = lld1(b, 4 * pad + idx); mxz = lld1(b, 5 * pad + idx);
+    } else {
+        mnx = gld1(b, (size_t)idx); mny = gld1(b, (size_t)pad + idx); mnz = gld1(b, (size_t)2 * pad + idx);
+        mxx = gld1(b, (size_t)3 * pad + idx); mxy = gld1(b, (size_t)4 * pad + idx); mxz = gld1(b, (size_t)5 * pad + idx);
+    }
+    const float x1 = (mnx - fr.o.x) * fr.ix, x2 = (mxx - fr.o.x) * fr.ix;
+    const float y1 = (mny - fr.o.y) * fr.iy, y2 = (mxy - fr.o.y) * fr.iy;
+    const float z1 = (mnz - fr.o.z) * fr.iz, z2 = (mxz - fr.o.z) * fr.iz;
+    const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+    const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+    bool h = tmax > tmin;
+    if (prune) h = h && !(tmin > far_t) && !(tmax < -fr.eps_t);
+    return h;
+}
+
+// What a block of pathwave_kernel staged in LDS for shape 0 (null = read through L2).  STAGE 0: nothing, 1: levels 2 and 1,
+// 2: all three levels, 3: the levels and the triangle records.
+struct FlatSrc {
+    const float* lvl[3]; const float4* tris;
+    int n[3], pad[3];           // entries and array stride of each level (copied out of the shape once: no reloads in the walk)
+    float bmin[3], bmax[3];     // the shape's bound (RShape::Aabb)
+};
+__device__ __forceinline__ FlatSrc flat_src_of(const RtwShapeDev& sh)
+{
+    FlatSrc g;
+    for (int l = 0; l < 3; l++) { g.lvl[l] = sh.flat[l]; g.n[l] = sh.flat_n[l]; g.pad[l] = sh.flat_pad[l]; }
+    g.tris = reinterpret_cast<const float4*>(sh.tris);
+    for (int k = 0; k < 3; k++) { g.bmin[k] = sh.bmin[k]; g.bmax[k] = sh.bmax[k]; }
+    return g;
+}
+
+// triangle tests of the n candidate leaves in lds_c[0..n) (ascending = preorder), 64 at a time.  A test must see
+// the segment left by every earlier accepted hit, so after an accept the later lanes are tested again with the
+// shortened segment (the reference tests them one after another).
+template <bool STATS, bool LDST>
+__device__ __forceinline__ void wave_triangles(const float4* __restrict__ tr4, const uint32_t* __restrict__ lds_c, int n, const Ray& r,
+                                               float& cur_dist, f3& hit_pos, int& hit_slot, bool& any, Counters& ct)
+{
+    const int lane = lane_id();
+    for (int j = 0; j < n; j += 64) {
+        const bool mine = j + lane < n;
+        const int leaf = mine ? (int)lldu(lds_c, j + lane) : 0;
+        float4 a, b, c, d;
+        if (LDST) { a = lld4(tr4, 4 * leaf); b = lld4(tr4, 4 * leaf + 1); c = lld4(tr4, 4 * leaf + 2); d = lld4(tr4, 4 * leaf + 3); }
+        else { a = gld4(tr4, 4 * (size_t)leaf); b = gld4(tr4, 4 * (size_t)leaf + 1); c = gld4(tr4, 4 * (size_t)leaf + 2); d = gld4(tr4, 4 * (size_t)leaf + 3); }
+        if (STATS) ct.tris += mine ? 1u : 0u;
+        int settled = -1;
+        for (;;) {
+            f3 cp = mk(0, 0, 0); float dist = 0.0f;
+            const bool acc = mine && lane > settled && triangle_test(r, cur_dist, a, b, c, d.x, cp, dist);
+            const unsigned long long am = __ballot(acc);
+            if (am == 0ull) break;
+            const int first = __ffsll((long long)am) - 1;
+            cur_dist = readlane_f(dist, first);
+            hit_pos = mk(readlane_f(cp.x, first), readlane_f(cp.y, first), readlane_f(cp.z, first));
+            hit_slot = __builtin_amdgcn_readlane(leaf, first);
+            any = true;
+            settled = first;
+        }
+    }
+}
+
+// KdTree::TestRayIntersection for ONE tame ray held identically by all 64 lanes.  Depth-first over the three flat
+// levels, four entries (64 children) per step, so the leaves come out in ascending slot order = preorder.
+template <bool STATS, int STAGE>
+__device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __restrict__ lds, const Ray& r, const FlatRay& fr, bool prune,
+                                               float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
+{
+    uint32_t* l2 = lds; uint32_t* l1 = lds + 64; uint32_t* lc = lds + 128;
+    const int lane = lane_id();
+    const int n0 = src.n[0], n1 = src.n[1], n2 = src.n[2];
+    bool any = false;
+    int ncand = 0;
+    for (int t0 = 0; t0 < n2; t0 += 64) {
+        float far_t = cur_dist + (fr.eps_t + 1.0e-4f * cur_dist);
+        const int i2 = t0 + lane;
+        const bool v2 = i2 < n2;
+        const bool h2 = v2 && flat_box_hit<(STAGE >= 1)>(src.lvl[2], src.pad[2], i2, fr, prune, far_t);
+        if (STATS) ct.boxes += v2 ? 1u : 0u;
+        const unsigned long long m2 = __ballot(h2);
+        if (m2 == 0ull) continue;
+        const int c2 = __popcll(m2) * 16;
+        wave_lds_sync();                            // every lane has read its l2 word of the previous round
+        if (h2) lstu(l2, mbcnt(m2), (uint32_t)i2);
+        wave_lds_sync();
+        for (int g2 = 0; g2 < c2; g2 += 64) {
+            const int g = g2 + lane;
+            const int i1 = (g < c2 ? (int)lldu(l2, g >> 4) : 0) * 16 + (g & 15);
+            const bool v1 = g < c2 && i1 < n1;
+            const bool h1 = v1 && flat_box_hit<(STAGE >= 1)>(src.lvl[1], src.pad[1], i1, fr, prune, far_t);
+            if (STATS) ct.boxes += v1 ? 1u : 0u;
+            const unsigned long long m1 = __ballot(h1);
+            if (m1 == 0ull) continue;
+            const int c1 = __popcll(m1) * 16;
+            wave_lds_sync();                        // every lane has read its l1 word of the previous round
+            if (h1) lstu(l1, mbcnt(m1), (uint32_t)i1);
+            wave_lds_sync();
+            for (int g1 = 0; g1 < c1; g1 += 64) {
+                const int gg = g1 + lane;
+                const int i0 = (gg < c1 ? (int)lldu(l1, gg >> 4) : 0) * 16 + (gg & 15);
+                const bool v0 = gg < c1 && i0 < n0;
+                const bool h0 = v0 && flat_box_hit<(STAGE >= 2)>(src.lvl[0], src.pad[0], i0, fr, prune, far_t);
+                if (STATS) ct.boxes += v0 ? 1u : 0u;
+                const unsigned long long m0 = __ballot(h0);
+                if (m0 == 0ull) continue;
+                if (h0) lstu(lc, ncand + mbcnt(m0), (uint32_t)i0);
+                ncand += __popcll(m0);
+                if (ncand > 64) {                   // the list holds 128: make room before the next 64
+                    wave_lds_sync();
+                    wave_triangles<STATS, (STAGE >= 3)>(src.tris, lc, ncand, r, cur_dist, hit_pos, hit_slot, any, ct);
+                    wave_lds_sync();
+                    ncand = 0;
+                    far_t = cur_dist + (fr.eps_t + 1.0e-4f * cur_dist);
+                }
+            }
+        }
+    }
+    if (ncand > 0) {
+        wave_lds_sync();
+        wave_triangles<STATS, (STAGE >= 3)>(src.tris, lc, ncand, r, cur_dist, hit_pos, hit_slot, any, ct);
+        wave_lds_sync();
+    }
+    return any;
+}
+
+// FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) of one ray held by the whole wave, without the shading
+// tail (only the record of the last shape that hit is read afterwards).  `shape0` describes shape 0 (its arrays staged
+// in LDS when STAGE > 0); later shapes are read from the scene.
+template <bool STATS, int STAGE>
+__device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __restrict__ sc, int n_shapes, bool prune, const FlatSrc& shape0,
+                                                       uint32_t* __restrict__ lds, const Ray& ray,
+                                                       int& hit_shape, int& hit_slot, f3& hit_pos, float& seg, Counters& ct)
+{
+    hit_shape = -1; hit_slot = -1; hit_pos = mk(0, 0, 0); seg = ray.dist;
+    const bool one = lane_id() == 0;
+    if (STATS && one) ct.rays++;
+    const bool tame = ray_is_tame(ray);
+    FlatRay fr;             // the three reciprocals of a tame ray, shared by the shape-bound test and the walk
+    fr.o = ray.o; fr.ix = 1.0f / ray.d.x; fr.iy = 1.0f / ray.d.y; fr.iz = 1.0f / ray.d.z;
+    fr.eps_t = 2.0e-5f * fmaxf(fabsf(fr.ix), fmaxf(fabsf(fr.iy), fabsf(fr.iz)));
+    for (int s = 0; s < n_shapes; s++) {
+        const FlatSrc g = (s == 0) ? shape0 : flat_src_of(sc->shapes[s]);
+        if (STATS && one) ct.boxes++;
+        bool in_bound;
+        if (tame) {         // RRay::TestIntersectionWithAabb with no axis skipped and no NaN: same operations, reciprocals reused
+            const float x1 = (g.bmin[0] - ray.o.x) * fr.ix, x2 = (g.bmax[0] - ray.o.x) * fr.ix;
+            const float y1 = (g.bmin[1] - ray.o.y) * fr.iy, y2 = (g.bmax[1] - ray.o.y) * fr.iy;
+            const float z1 = (g.bmin[2] - ray.o.z) * fr.iz, z2 = (g.bmax[2] - ray.o.z) * fr.iz;
+            const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+            const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+            in_bound = tmax > tmin;
+        } else {
+            float t0, t1;
+            in_bound = slab_exact(ray, g.bmin[0], g.bmin[1], g.bmin[2], g.bmax[0], g.bmax[1], g.bmax[2], t0, t1);
+        }
+        if (!in_bound) continue;
+        float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
+        bool any;
+        if (tame && g.n[0] > 0) {
+            if (STAGE > 0 && s == 0) any = wave_walk_flat<STATS, STAGE>(g, lds, ray, fr, prune, cur, pos, slot, ct);
+            else any = wave_walk_flat<STATS, 0>(g, lds, ray, fr, prune, cur, pos, slot, ct);
+        } else {                    // a direction component below FLT_EPSILON, NaN, ...: the reference's own walk, all lanes alike
+            const RtwShapeDev& sh = sc->shapes[s];
+            Counters walk = { 0, 0, 0, 0, 0, 0 };
+            if (tame) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, prune, cur, pos, slot, walk);
+            else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, false, cur, pos, slot, walk);
+            if (STATS && one) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
+        }
+        if (any) { seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos; }
+    }
+}
+
+// ---- primary rays through the screen bins ------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
+                                                           uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
+    __syncthreads();
+    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = p.width * p.height;
+    const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
+    const bool live = pixel < npix;
+    // the wave's bin: all its pixels lie in one tile of the screen's bin grid (tile rows never straddle a bin row)
+    const unsigned long long live_mask = __ballot(live);
+    int bin = 0;
+    if (live_mask != 0ull) {
+        const int first_pixel = __builtin_amdgcn_readlane(pixel, __ffsll((long long)live_mask) - 1);
+        const int fy = first_pixel / p.width, fx = first_pixel - fy * p.width;
+        bin = (fy >> (6 - p.tile_shift)) * p.tiles_per_row + (fx >> p.tile_shift);      // tile_w = 1 << tile_shift, tile_h = 64 / tile_w
+    }
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    const uint32_t phase = table_phase(p.seed);
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    // Can any sample of this wave's pixels hit anything?  Only if a shape has leaves in the tile's bin (or has no bins).
+    // Then every sample's colour is kept (resolve_kernel sums a pending pixel's samples in order); else nothing is kept.
+    bool near_wave = false;
+    for (int k = 0; k < n_shapes; k++) {
+        const uint32_t* __restrict__ boff = p.bins[k].off;
+        near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);
+    }
+    f3 csum = mk(0, 0, 0);                                   // s[0] + s[1] + ... in sample order, as the reference adds them
+    bool pending = false;
+    for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)p.pass_index, (uint32_t)i);
+        const Ray ray = camera_ray(p.width, p.height, live ? pixel : 0, i, rng);
+        if (STATS && live) ct.cams++;
+        f3 si = mk(0, 0, 0);
+        bool queue_it = false;
+        float4 hr0 = make_float4(0.f, 0.f, 0.f, 0.f), hr1 = hr0;
+        if (p.max_bounce != 0) {                             // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+            // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
+            int hit_shape = -1, hit_slot = -1;
+            f3 hit_pos = mk(0, 0, 0);
+            float seg = ray.dist;
+            if (STATS && live) ct.rays++;
+            const bool tame = ray_is_tame(ray);
+            for (int k = 0; k < n_shapes; k++) {
+                const RtwShapeDev& sh = sc->shapes[k];
+                float t0, t1;
+                const bool inbox = live && slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1);
+                if (STATS && live) ct.boxes++;
+                if (__ballot(inbox) == 0ull) continue;
+                float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
+                bool any = false;
+                const uint32_t* __restrict__ boff = p.bins[k].off;
+                if (boff == nullptr) {                       // no bins for this shape: packet walk of its tree
+                    any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
+                } else {
+                    const bool active = inbox && tame;
+                    const uint32_t* __restrict__ bent = p.bins[k].ent;
+                    const int e0 = (int)cldu(boff, bin), e1 = (int)cldu(boff, bin + 1);
+                    const float4* nd4 = reinterpret_cast<const float4*>(sh.nodes);
+                    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+                    const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+                    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+                    for (int e = e0; e < e1; e++) {
+                        const int node = __builtin_amdgcn_readfirstlane((int)cldu(bent, e));
+                        const float4 lo = cld4(nd4, 2 * node), hi = cld4(nd4, 2 * node + 1);
+                        const int leaf = __float_as_int(hi.w);
+                        const float x1 = (lo.x - ray.o.x) * ix, x2 = (hi.x - ray.o.x) * ix;
+                        const float y1 = (lo.y - ray.o.y) * iy, y2 = (hi.y - ray.o.y) * iy;
+                        const float z1 = (lo.z - ray.o.z) * iz, z2 = (hi.z - ray.o.z) * iz;
+                        const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                        const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                        bool hit = active && (tmax > tmin);
+                        if (prune) hit = hit && !(tmin > cur + (eps_t + 1.0e-4f * cur)) && !(tmax < -eps_t);
+                        if (STATS) ct.boxes += active ? 1u : 0u;
+                        if (__ballot(hit) == 0ull) continue;
+                        const float4 a = cld4(tr4, 4 * leaf), b = cld4(tr4, 4 * leaf + 1), c = cld4(tr4, 4 * leaf + 2), d = cld4(tr4, 4 * leaf + 3);
+                        if (hit) {
+                            if (STATS) ct.tris++;
+                            f3 cp; float dist;
+                            if (triangle_test(ray, cur, a, b, c, d.x, cp, dist)) { cur = dist; pos = cp; slot = leaf; any = true; }
+                        }
+                    }
+                }
+                if (any) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
+            }
+            if (live && !tame) {    // a handful per frame (a direction component below FLT_EPSILON): the reference's own walk, lane by lane
+                hit_shape = -1; seg = ray.dist;
+                for (int k = 0; k < n_shapes; k++) {
+                    const RtwShapeDev& sh = sc->shapes[k];
+                    float t0, t1;
+                    if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+                    float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
+                    Counters walk = { 0, 0, 0, 0, 0, 0 };
+                    if (tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, false, cur, pos, slot, walk)) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
+                    if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
+                }
+            }
+            if (live) {
+                if (hit_shape < 0) {
+                    si = sky_color(ray.d.y);
+                } else {
+                    queue_it = true;
+                    hr0 = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
+                    hr1 = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
+                }
+            }
+        }
+        csum = csum + si;
+        if (live && near_wave && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
+        pending = pending || queue_it;
+        const uint32_t at = wave_push_slot(pb.queue, &pb.counters[0], queue_it, (uint32_t)wi * 4u + (uint32_t)i);
+        if (at != 0xFFFFFFFFu && at < pb.capacity) { pb.hitslot[(size_t)at * 2] = hr0; pb.hitslot[(size_t)at * 2 + 1] = hr1; }
+    }
+    if (live && !pending) {
+        const f3 c = csum / (float)p.sub_samples;
+        resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
+    }
+    wave_push(pb.pend, &pb.counters[1], pending, (uint32_t)wi);
+    if (STATS) flush_counters(sc, ct);
+}
+
+// ---- a wave carries `wave_paths` paths to their end ---------------------------------------------------------------
+// the block copies what STAGE says of shape 0 into LDS behind the waves' lists (whole block, ends with a barrier)
+template <int STAGE, int NT>
+__device__ __forceinline__ FlatSrc stage_shape0(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ wave_dyn)
+{
+    const RtwShapeDev& s0 = sc->shapes[0];
+    FlatSrc staged = flat_src_of(s0);
+    if (STAGE > 0) {
+        float* dst = reinterpret_cast<float*>(wave_dyn + (NT / 64) * RTW_WAVE_LDS_WORDS);
+        for (int l = 2; l >= (STAGE >= 2 ? 0 : 1); l--) {
+            const int words = 6 * staged.pad[l];        // a multiple of 4
+            const float4* src4 = reinterpret_cast<const float4*>(s0.flat[l]);
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            for (int i = (int)threadIdx.x; i < words / 4; i += NT) dst4[i] = gld4(src4, (size_t)i);
+            staged.lvl[l] = dst;
+            dst += words;
+        }
+        if (STAGE >= 3) {
+            const float4* src4 = reinterpret_cast<const float4*>(s0.tris);
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            for (int i = (int)threadIdx.x; i < s0.n_tris * 4; i += NT) dst4[i] = gld4(src4, (size_t)i);
+            staged.tris = dst4;
+        }
+        __syncthreads();
+    }
+    return staged;
+}
+
+// ---- one round of secondary segments: a wave per ray -----------------------------------------------------------------
+// The wavefront pipeline's trace step (see trace_kernel) with the whole wave on one ray: the ray comes in through scalar
+// loads, the walk is wave_walk_flat on the arrays the block staged in LDS.  Persistent blocks, one per CU when staged.
+template <bool STATS, int STAGE, int NT>
+__global__ __launch_bounds__(NT) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
+{
+    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
+    const uint32_t n = pb.counters[4 + round];
+    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;         // (whole block) no ray left for this block's first wave
+    uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
+    const FlatSrc staged = stage_shape0<STAGE, NT>(sc, wave_dyn);
+    const uint32_t* __restrict__ src = wf_list(pb, round & 1);
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t k = wave; k < n; k += nwaves) {
+        const int ku = __builtin_amdgcn_readfirstlane((int)k);
+        const int q = (int)cldu(src, ku);
+        const float4 s0 = cld4(pb.state, q * 3), s1 = cld4(pb.state, q * 3 + 1);
+        Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+        int hs, slot; f3 pos; float seg;
+        wave_find_intersection<STATS, STAGE>(sc, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
+        if (lane_id() == 0) {
+            pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
+            pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
+        }
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+template <bool STATS, int STAGE, int NT>
+__global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathwave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p)
+{
+    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
+    const uint32_t B = (uint32_t)p.wave_paths;
+    const uint32_t nq = pb.counters[0];
+    const uint32_t n = nq < pb.capacity ? nq : pb.capacity;
+    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) * B >= n) return;     // (whole block) the grid is sized from the previous pass's queue length
+    uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
+    const FlatSrc staged = stage_shape0<STAGE, NT>(sc, wave_dyn);
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    const int lane = lane_id();
+    const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);
+    const int npix = p.width * p.height;
+    const uint32_t phase = table_phase(p.seed);
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
+    for (uint32_t base = wave * B; base < n; base += nwaves * B) {
+        const uint32_t q = base + (uint32_t)lane;
+        bool alive = (uint32_t)lane < B && q < n;
+        uint32_t pid = 0;
+        PathRng rng; rng.key = 0; rng.counter = 0; rng.table_base = 0; rng.table_reads = 0;
+        Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.dist = 0.0f;
+        int depth = 0, nlev = 0;
+        bool have_hit = false;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (alive) {
+            const uint32_t qe = pb.queue[q];
+            pid = qe & 0x7FFFFFFFu;
+            const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
+            const int pixel = work_to_pixel(p, wi);
+            rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
+            ray = camera_ray(p.width, p.height, pixel, sub, rng);
+            depth = p.max_bounce;
+            have_hit = !(qe >> 31);                      // else: an untame camera ray, its first segment is traced like any other
+            if (have_hit) { r0 = pb.hitslot[(size_t)q * 2]; r1 = pb.hitslot[(size_t)q * 2 + 1]; }
+        }
+        LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
+        for (;;) {
+            bool need_trace = false;
+            if (alive) {
+                f3 L = mk(0, 0, 0);
+                bool done = false;
+                if (have_hit) {
+                    const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
+                    if (hs < 0) { L = sky_color(ray.d.y); done = true; }
+                    else {
+                        const RtwShapeDev& sh = sc->shapes[hs];
+                        Hit h; int tri_index;
+                        mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+                        if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
+                        else {
+                            Ray out = ray;
+                            if (p.preview) {
+                                const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
+                                L = mk(0, 0, 0) + pv.att * h.color; done = true;
+                            } else {
+                                const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
+                                if (rng.random() <= h.alpha) {
+                                    if (all_nonzero(b.att)) {
+                                        lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
+                                        lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                                        lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+                                        nlev++;
+                                        ray = out;
+                                    } else { L = mk(0, 0, 0) + b.em; done = true; }
+                                } else {                 // transparent texel: same direction, remaining distance, no colour factor
+                                    lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+                                    nlev++;
+                                    const float rd = ray.dist - h.dist;
+                                    ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
+                                }
+                                if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
+                            }
+                        }
+                    }
+                }
+                if (done) {
+                    for (int kk = nlev - 1; kk >= 0; kk--) {
+                        const float4 a = lv.at(kk, 0);
+                        if (__float_as_int(a.w) == 0) {
+                            const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
+                            L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
+                        } else {
+                            L = mk(0, 0, 0) + L;
+                        }
+                    }
+                    pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+                    alive = false;
+                } else {
+                    need_trace = true;
+                }
+            }
+            unsigned long long m = __ballot(need_trace);
+            if (m == 0ull) break;
+            while (m != 0ull) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                Ray ur;
+                ur.o = mk(readlane_f(ray.o.x, l), readlane_f(ray.o.y, l), readlane_f(ray.o.z, l));
+                ur.d = mk(readlane_f(ray.d.x, l), readlane_f(ray.d.y, l), readlane_f(ray.d.z, l));
+                ur.dist = readlane_f(ray.dist, l);
+                int hs, slot; f3 pos; float seg;
+                wave_find_intersection<STATS, STAGE>(sc, n_shapes, prune, staged, lds, ur, hs, slot, pos, seg, ct);
+                if (lane == l) {
+                    r0 = make_float4(pos.x, pos.y, pos.z, seg);
+                    r1 = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
+                    have_hit = true;
+                }
+            }
+        }
+    }
+    if (STATS) flush_counters(sc, ct);
+}

@@ -64,7 +64,7 @@ struct rtw_context {
     bool stats_enabled = false;
     void* d_workspace = nullptr;        // per-launch queues / level store of the bounce recursion (grown on demand)
     size_t workspace_bytes = 0;
-    int pipeline = 1;                   // 1 = primary / path / resolve launches (default), 0 = one kernel, one thread per pixel
+    int pipeline = 3;                   // 3 = screen bins + a wave per secondary ray (default), 2 = a launch per bounce, 1 = primary / path / resolve, 0 = one kernel
     int packets = 1;                    // pipeline 1: camera rays traced as 64-ray packets inside the primary kernel
     int path_lanes = 16;                // pipeline 1: lanes per ray in the path kernel (16, 4 or 1)
     uint32_t* h_counters = nullptr;     // pinned: queue / pending lengths copied back after each pass
@@ -74,6 +74,10 @@ struct rtw_context {
     long long known_shape = -1;         // launch shape of known_paths
     int known_paths = -1;               // queue length of the latest pass whose copy has completed
     int known_rounds[32];               // wavefront: trace-list lengths of that pass
+    int cu_count = 256;
+    int wave_stage = -1;                // pipeline 3: LDS staging of shape 0 in the path kernel (-1 = as much as fits, 0..3 = fixed)
+    int wave_fused = 0;                 // pipeline 3: 1 = one kernel carries the paths to their end, 0 = a launch per bounce
+    int wave_paths = 0;                 // pipeline 3: paths per wave of the path kernel (0 = chosen from the queue length)
     int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
     int kernel_timing = 0;              // 1: record events around the three kernels of each pass
     hipEvent_t timing_events[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -87,6 +91,9 @@ struct rtw_scene {
     int traversal = 1;
     RtwSceneDev* d_scene = nullptr;
     std::vector<void*> allocs;
+    // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
+    struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; };
+    std::vector<BinSet> bin_sets;
 };
 
 struct rtw_framebuffer {
@@ -139,6 +146,7 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipSetDevice(device_index));
     std::unique_ptr<rtw_context> c(new rtw_context());
     c->device = device_index;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_index) == hipSuccess && cus > 0) c->cu_count = cus; }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     const std::vector<float>& tab = host_unit_table();
@@ -188,8 +196,23 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
 {
     if (!ctx || !name) return fail(RTW_ERR_INVALID, "null argument");
     if (std::strcmp(name, "pipeline") == 0) {
-        if (value < 0 || value > 2) return fail(RTW_ERR_INVALID, "pipeline must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(RTW_ERR_INVALID, "pipeline must be 0, 1, 2 or 3");
         ctx->pipeline = value;
+        return RTW_OK;
+    }
+    if (std::strcmp(name, "wave_stage") == 0) {
+        if (value < -1 || value > 3) return fail(RTW_ERR_INVALID, "wave_stage must be -1 (automatic) or 0..3");
+        ctx->wave_stage = value;
+        return RTW_OK;
+    }
+    if (std::strcmp(name, "wave_fused") == 0) {
+        if (value != 0 && value != 1) return fail(RTW_ERR_INVALID, "wave_fused must be 0 or 1");
+        ctx->wave_fused = value;
+        return RTW_OK;
+    }
+    if (std::strcmp(name, "wave_paths") == 0) {
+        if (value < 0 || value > 64) return fail(RTW_ERR_INVALID, "wave_paths must be 0 (automatic) or 1..64");
+        ctx->wave_paths = value;
         return RTW_OK;
     }
     if (std::strcmp(name, "packets") == 0) { ctx->packets = value ? 1 : 0; return RTW_OK; }
@@ -377,7 +400,7 @@ int rtw_scene_commit(rtw_scene* scene)
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
     if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
     if (!scene->ctx) {      // host-only scene: build the flattened trees for inspection, nothing to upload
-        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_quads(*m); }
+        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_quads(*m); rtw::build_flat(*m); }
         scene->committed = true;
         return RTW_OK;
     }
@@ -406,6 +429,11 @@ int rtw_scene_commit(rtw_scene* scene)
         if (m.wide_depth <= RTW_WIDE_STACK && m.wides.size() < 65536) {
             if ((rc = upload(scene, m.wides, &d.wides)) != RTW_OK) return rc;
             d.n_wides = (int)m.wides.size(); d.wide_depth = m.wide_depth;
+        }
+        rtw::build_flat(m);
+        for (int l = 0; l < 3; l++) {
+            if ((rc = upload(scene, m.flat[l], &d.flat[l])) != RTW_OK) return rc;
+            d.flat_n[l] = m.flat_n[l]; d.flat_pad[l] = m.flat_pad[l];
         }
         if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
         if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
@@ -632,6 +660,60 @@ int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb)
     return RTW_OK;
 }
 
+// Bins of every shape of the scene for one frame size and bin shape, built and uploaded on first use.
+static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bin_h, RtwBinsDev** out)
+{
+    for (const rtw_scene::BinSet& b : scene->bin_sets)
+        if (b.width == width && b.height == height && b.bin_w == bin_w && b.bin_h == bin_h) { *out = b.d_bins; return RTW_OK; }
+    std::vector<RtwBinsDev> h(scene->meshes.size());
+    for (size_t s = 0; s < scene->meshes.size(); s++) {
+        std::vector<uint32_t> off, ent;
+        h[s].off = nullptr; h[s].ent = nullptr;
+        if (!rtw::build_bins(*scene->meshes[s], width, height, bin_w, bin_h, off, ent)) continue;
+        int rc;
+        if ((rc = upload(scene, off, &h[s].off)) != RTW_OK) return rc;
+        if ((rc = upload(scene, ent, &h[s].ent)) != RTW_OK) return rc;
+    }
+    const RtwBinsDev* d = nullptr;
+    int rc = upload(scene, h, &d); if (rc != RTW_OK) return rc;
+    scene->bin_sets.push_back({ width, height, bin_w, bin_h, const_cast<RtwBinsDev*>(d) });
+    *out = const_cast<RtwBinsDev*>(d);
+    return RTW_OK;
+}
+
+// Tiled work mapping of the bins + wave pipeline: the rows of the launch are cut into tile_w x tile_h tiles (64 pixels,
+// one wave each) that coincide with bins of the screen.  Returns false when the launch's rows cannot be tiled that way.
+static bool choose_tiles(RtwRenderParams& p)
+{
+    const int W = p.width, H = p.height;
+    if (W <= 0 || H <= 0) return false;
+    long long vrows;                     // rows of this launch (virtual rows of the rank's tasks, or screen rows of the range)
+    int row0 = 0;
+    if (p.world <= 1 && p.task_rows == 0) {
+        if (p.begin % W != 0 || p.count % W != 0) return false;
+        row0 = p.begin / W; vrows = p.count / W;
+    } else if (p.world <= 1) {
+        row0 = 0; vrows = H;
+    } else {
+        vrows = p.count / W;
+    }
+    for (int th = 4; th >= 1; th >>= 1) {
+        const int tw = 64 / th;
+        if (W % tw != 0 || H % th != 0 || row0 % th != 0) continue;
+        if (p.world > 1 && p.task_rows % th != 0) continue;
+        if (p.world <= 1 && vrows % th != 0) continue;
+        const long long bands = (vrows + th - 1) / th;
+        const long long count = bands * (W / tw) * 64;
+        if (count > INT32_MAX) return false;
+        p.tile_w = tw; p.tile_h = th; p.tiles_per_row = W / tw;
+        p.tile_shift = tw == 16 ? 4 : (tw == 32 ? 5 : 6);
+        p.row0 = row0; p.nrows = (int)vrows;
+        p.count = (int)count;
+        return true;
+    }
+    return false;
+}
+
 // ---- the hot path -------------------------------------------------------------------------------------------
 static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams& p, int max_bounce, int use_base_color,
                          int pass_index, int sub_samples, uint32_t seed)
@@ -643,10 +725,22 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     p.width = fb->width; p.height = fb->height;
     p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
     hipError_t e;
-    if (scene->ctx->pipeline >= 1) {
+    // the bins + wave pipeline needs whole rows, the flat hierarchy (traversal != 0) and a frame that tiles; else pipeline 2
+    int pipeline = scene->ctx->pipeline;
+    if (pipeline == 3) {
+        RtwRenderParams tiled = p;
+        RtwBinsDev* d_bins = nullptr;
+        if (scene->traversal != 0 && scene->ctx->packets != 0 && choose_tiles(tiled) &&
+            scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &d_bins) == RTW_OK) {
+            p = tiled; p.bins = d_bins;
+        } else {
+            pipeline = 2;
+        }
+    }
+    if (pipeline >= 1) {
         rtw::PipelineLayout layout;
         rtw::pipeline_workspace_bytes(p.count, max_bounce, &layout);
-        int rc = ensure_workspace(scene->ctx, scene->ctx->pipeline == 2 ? layout.wf_total : layout.total); if (rc != RTW_OK) return rc;
+        int rc = ensure_workspace(scene->ctx, pipeline >= 2 ? layout.wf_total : layout.total); if (rc != RTW_OK) return rc;
         int lds_quads = 0;
         if (scene->ctx->path_lanes == 4 && scene->traversal != 0 && !scene->meshes.empty() && scene->meshes[0]->quad_depth <= RTW_QUAD_STACK) {
             lds_quads = (int)scene->meshes[0]->quads.size();
@@ -671,7 +765,31 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         tune.expected_paths = (cx->known_shape == shape) ? cx->known_paths : -1;
         for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
         p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
-        p.wavefront = (cx->pipeline == 2 && p.packets) ? 1 : 0;
+        p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
+        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused;
+        if (p.wavefront == 2 && !scene->meshes.empty()) {
+            // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
+            const rtw::HostMesh& m0 = *scene->meshes[0];
+            const size_t budget = 160 * 1024 - 16 * 1024 - 2048;
+            const size_t b1 = (size_t)6 * 4 * ((size_t)m0.flat_pad[2] + (size_t)m0.flat_pad[1]);
+            const size_t b2 = b1 + (size_t)6 * 4 * (size_t)m0.flat_pad[0];
+            const size_t b3 = b2 + m0.tris.size() * sizeof(RtwTri);
+            int stage = m0.flat_n[0] <= 0 ? 0 : (b3 <= budget ? 3 : (b2 <= budget ? 2 : (b1 <= budget ? 1 : 0)));
+            if (cx->wave_stage >= 0 && cx->wave_stage < stage) stage = cx->wave_stage;
+            tune.wave_stage = stage;
+            tune.wave_stage_bytes = stage == 3 ? b3 : (stage == 2 ? b2 : (stage == 1 ? b1 : 0));
+        }
+        if (p.wavefront == 2) {
+            int B = cx->wave_paths;
+            if (B == 0) {       // enough waves to fill the chip (1024 SIMDs, several waves each), at most 16 paths per wave
+                const int expect = tune.expected_paths >= 0 ? tune.expected_paths : 1 << 20;
+                const int resident = tune.wave_stage > 0 ? cx->cu_count * 16 : 8192;
+                B = (expect + resident - 1) / resident;
+                if (B < 2) B = 2;
+                if (B > 32) B = 32;
+            }
+            p.wave_paths = B;
+        }
         tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
         tune.path_variant = cx->path_variant;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);

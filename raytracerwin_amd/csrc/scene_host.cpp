@@ -410,6 +410,93 @@ void build_quads(HostMesh& m)
 }
 
 // ---------------------------------------------------------------------------------------
+// Flat hierarchy.  Leaves in preorder; level l + 1 entry k = union of level l entries [16k, 16k + 16).
+// A ray whose line meets a leaf's own box meets every union that contains it (the slab test is monotone
+// in the bounds), so testing unions first only culls; the leaf's own box then gets the reference's test.
+// ---------------------------------------------------------------------------------------
+void build_flat(HostMesh& m)
+{
+    for (int l = 0; l < 3; l++) { m.flat[l].clear(); m.flat_n[l] = m.flat_pad[l] = 0; }
+    const int n0 = (int)m.tris.size();
+    if (n0 == 0) return;
+    int n = n0;
+    for (int l = 0; l < 3; l++) {
+        m.flat_n[l] = n;
+        m.flat_pad[l] = ((n + 63) / 64) * 64 + 64;          // whole waves may read past n (values unused)
+        m.flat[l].assign((size_t)6 * (size_t)m.flat_pad[l], 0.0f);
+        n = (n + 15) / 16;
+    }
+    auto at = [&](int l, int c, int i) -> float& { return m.flat[l][(size_t)c * (size_t)m.flat_pad[l] + (size_t)i]; };
+    for (const RtwNode& nd : m.nodes) {
+        if (nd.tri < 0) continue;
+        at(0, 0, nd.tri) = nd.min_x; at(0, 1, nd.tri) = nd.min_y; at(0, 2, nd.tri) = nd.min_z;
+        at(0, 3, nd.tri) = nd.max_x; at(0, 4, nd.tri) = nd.max_y; at(0, 5, nd.tri) = nd.max_z;
+    }
+    for (int l = 1; l < 3; l++) {
+        for (int k = 0; k < m.flat_n[l]; k++) {
+            for (int c = 0; c < 3; c++) {
+                float lo = FLT_MAX, hi = -FLT_MAX;
+                for (int i = 16 * k; i < 16 * k + 16 && i < m.flat_n[l - 1]; i++) {
+                    if (at(l - 1, c, i) < lo) lo = at(l - 1, c, i);
+                    if (at(l - 1, c + 3, i) > hi) hi = at(l - 1, c + 3, i);
+                }
+                at(l, c, k) = lo; at(l, c + 3, k) = hi;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Screen-space bins of the reference's fixed camera.  Pixel (x, y), sub-sample offset (ox, oy) looks along
+// (dx + ox, dy + oy, -0.5) with dx = -(x - W/2) / (2W) * (W/H), dy = -(y - H/2) / (2H) (Src/RayTracerProgram.cpp:141-165),
+// so a point q (relative to the camera, q.z < 0) is seen at x = W/2 + H q.x / q.z, y = H/2 + H q.y / q.z (the offsets
+// move a sample by less than half a pixel).  A leaf joins every bin that its box's projected rectangle, grown by a
+// one-pixel margin, touches.  This only has to be a superset: the kernel still runs the reference's box test per ray.
+// ---------------------------------------------------------------------------------------
+bool build_bins(const HostMesh& m, int width, int height, int bin_w, int bin_h, std::vector<uint32_t>& off, std::vector<uint32_t>& ent)
+{
+    off.clear(); ent.clear();
+    if (width <= 0 || height <= 0 || bin_w <= 0 || bin_h <= 0 || width % bin_w != 0 || height % bin_h != 0) return false;
+    const int bx = width / bin_w, by = height / bin_h;
+    const double cx = (double)(width / 2), cy = (double)(height / 2), H = (double)height;
+    struct Rect { int node, x0, x1, y0, y1; };
+    std::vector<Rect> rects;
+    rects.reserve(m.tris.size());
+    for (size_t i = 0; i < m.nodes.size(); i++) {
+        const RtwNode& nd = m.nodes[i];
+        if (nd.tri < 0) continue;
+        const double zmax = (double)nd.max_z - 7.0;
+        if (!(zmax < -0.01)) return false;                      // not wholly in front of the camera: no bins for this mesh
+        double xa = 1e300, xb = -1e300, ya = 1e300, yb = -1e300;
+        for (int c = 0; c < 8; c++) {
+            const double qx = (double)((c & 1) ? nd.max_x : nd.min_x), qy = (double)((c & 2) ? nd.max_y : nd.min_y);
+            const double qz = (double)((c & 4) ? nd.max_z : nd.min_z) - 7.0;
+            const double sx = cx + H * qx / qz, sy = cy + H * qy / qz;
+            if (sx < xa) xa = sx; if (sx > xb) xb = sx;
+            if (sy < ya) ya = sy; if (sy > yb) yb = sy;
+        }
+        if (!(xa == xa) || !(ya == ya)) return false;
+        const double margin = 1.0;
+        double fx0 = std::floor(xa - margin), fx1 = std::ceil(xb + margin), fy0 = std::floor(ya - margin), fy1 = std::ceil(yb + margin);
+        if (fx1 < 0 || fy1 < 0 || fx0 > width - 1 || fy0 > height - 1) continue;      // off screen
+        if (fx0 < 0) fx0 = 0; if (fy0 < 0) fy0 = 0;
+        if (fx1 > width - 1) fx1 = width - 1; if (fy1 > height - 1) fy1 = height - 1;
+        rects.push_back({ (int)i, (int)fx0 / bin_w, (int)fx1 / bin_w, (int)fy0 / bin_h, (int)fy1 / bin_h });
+    }
+    off.assign((size_t)bx * (size_t)by + 1, 0u);
+    for (const Rect& r : rects)
+        for (int y = r.y0; y <= r.y1; y++)
+            for (int x = r.x0; x <= r.x1; x++) off[(size_t)y * (size_t)bx + (size_t)x + 1]++;
+    for (size_t i = 1; i < off.size(); i++) off[i] += off[i - 1];
+    ent.assign(off.back() ? off.back() : 1, 0u);
+    std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+    for (const Rect& r : rects)                                  // rects are in ascending node order, so every bin's list is too
+        for (int y = r.y0; y <= r.y1; y++)
+            for (int x = r.x0; x <= r.x1; x++) ent[fill[(size_t)y * (size_t)bx + (size_t)x]++] = (uint32_t)r.node;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
 // random stream + host-generated tables
 // ---------------------------------------------------------------------------------------
 namespace {

@@ -303,18 +303,25 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     W, H = 1280, 720
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
     out = []
-    for mode, packets, lanes in ((0, 0, 4), (1, 0, 4), (1, 0, 1), (1, 1, 4), (1, 1, 1), (1, 0, 16), (1, 1, 16), (2, 1, 16)):
+    # (pipeline, packets, path_lanes, wave_fused, wave_stage): 3 = screen bins + a wave per secondary ray
+    for mode, packets, lanes, fused, stage in ((0, 0, 4, 0, -1), (1, 0, 4, 0, -1), (1, 0, 1, 0, -1), (1, 1, 4, 0, -1), (1, 1, 1, 0, -1), (1, 0, 16, 0, -1),
+                                               (1, 1, 16, 0, -1), (2, 1, 16, 0, -1), (3, 1, 16, 0, -1), (3, 1, 16, 1, -1), (3, 1, 16, 0, 0),
+                                               (3, 1, 16, 0, 1), (3, 1, 16, 1, 2)):
         ctx.set_option("pipeline", mode)
         ctx.set_option("packets", packets)
         ctx.set_option("path_lanes", lanes)
+        ctx.set_option("wave_fused", fused)
+        ctx.set_option("wave_stage", stage)
         ctx.stats_enable(True)
         ctx.stats_reset()
         a, b = render_frame(ctx, s, W, H, ns, depth, preview, 4321, 0, 2)
         out.append((a, b, ctx.stats()))
         ctx.stats_enable(False)
-    ctx.set_option("pipeline", 1)
+    ctx.set_option("pipeline", 3)
     ctx.set_option("packets", 1)
     ctx.set_option("path_lanes", 16)
+    ctx.set_option("wave_fused", 0)
+    ctx.set_option("wave_stage", -1)
     keys = ("rays", "shaded_hits", "tex_samples", "camera_rays")     # box / triangle test counts depend on the walk
     for o in out[1:]:
         assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
