@@ -33,6 +33,7 @@ struct PipelineTuning {
     int wave_stage;        // bins + wave pipeline: what pathwave_kernel's blocks stage in LDS for shape 0 (0 nothing .. 3 levels + triangles)
     size_t wave_stage_bytes;   // bytes of those arrays
     int wave_fused;        // 1: pathwave_kernel carries the paths to their end, 0: one shade + one wave-per-ray trace launch per bounce
+    int primary_blocks_per_cu;   // bins + wave pipeline: blocks per CU of the persistent primary kernel
     int wave_blocks;       // staged variants: blocks to launch at most (one per CU)
     hipEvent_t* timing;    // null, or 4 events recorded before the primary kernel and after each of the three kernels
 };

@@ -1058,6 +1058,23 @@ __device__ __forceinline__ Ray camera_ray(int width, int height, int pixel, int 
     return r;
 }
 
+// the same ray from the host's per-column / per-row tables (tiled pipelines): dx and dy hold exactly the floats above
+__device__ __forceinline__ Ray camera_ray_xy(const RtwRenderParams& p, int x, int y, int i, PathRng& rng)
+{
+    const float dx = p.cam_dx[x], dy = p.cam_dy[y];
+    const float inv_pixel_radius = 1.0f / (p.width * 4);
+    const float offset_radius = inv_pixel_radius * 0.5f;
+    float ox = (i & 1) ? inv_pixel_radius : 0.0f;
+    float oy = (i & 2) ? inv_pixel_radius : 0.0f;
+    ox += (rng.random() - 0.5f) * offset_radius;
+    oy += (rng.random() - 0.5f) * offset_radius;
+    Ray r;
+    r.o = mk(0, 0, 7.0f);
+    r.d = normalized(mk(dx + ox, dy + oy, -0.5f));
+    r.dist = 1000.0f;
+    return r;
+}
+
 // 8-bit value of MakePixelColor(LinearToGamma(c)) for one channel: the largest k with thr[k] <= c.
 // A fast exp2/log2 guess is corrected against the exact host thresholds, so the guess quality
 // affects speed only.
@@ -1071,9 +1088,29 @@ __device__ __forceinline__ uint32_t gamma_channel(const float* __restrict__ thr,
     while (k > 0 && thr[k] > c) k--;
     return (uint32_t)k;
 }
+// guess of gamma_channel's k (quality affects speed only)
+__device__ __forceinline__ int gamma_guess(float c)
+{
+    int k = (int)(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 2.2f)) * 255.0f);
+    return k < 0 ? 0 : (k > 254 ? 254 : k);
+}
+// the largest k with thr[k] <= c, given the guess g in 0..254 and the two table entries around it
+__device__ __forceinline__ uint32_t gamma_fix(const float* __restrict__ thr, float c, int g, float t0, float t1)
+{
+    if (!(c > 0.0f)) return 0u;
+    if (c >= 1.0f) return 255u;
+    if (t0 <= c && !(t1 <= c)) return (uint32_t)g;          // thr[g] <= c < thr[g + 1]: the guess was right (almost always)
+    int k = g;
+    while (k < 255 && thr[k + 1] <= c) k++;
+    while (k > 0 && thr[k] > c) k--;
+    return (uint32_t)k;
+}
 __device__ __forceinline__ uint32_t pack_pixel(const float* __restrict__ thr, f3 c)
 {
-    return (255u << 24) | (gamma_channel(thr, c.x) << 16) | (gamma_channel(thr, c.y) << 8) | gamma_channel(thr, c.z);
+    // the three channels' table reads are issued together (one LDS round trip instead of six dependent ones)
+    const int gx = gamma_guess(c.x), gy = gamma_guess(c.y), gz = gamma_guess(c.z);
+    const float x0 = thr[gx], x1 = thr[gx + 1], y0 = thr[gy], y1 = thr[gy + 1], z0 = thr[gz], z1 = thr[gz + 1];
+    return (255u << 24) | (gamma_fix(thr, c.x, gx, x0, x1) << 16) | (gamma_fix(thr, c.y, gy, y0, y1) << 8) | gamma_fix(thr, c.z, gz, z0, z1);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -1110,24 +1147,29 @@ __device__ __forceinline__ void resolve_pixel(const float* __restrict__ thr, flo
         const f3 sum = mk(a.x, a.y, a.z) + c;
         const int n = __float_as_int(a.w) + 1;
         accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
-        argb[pixel] = pack_pixel(thr, sum / (float)n);
+        argb[pixel] = pack_pixel(thr, n == 1 ? sum : sum / (float)n);       // x / 1.0f == x: the first pass skips three divides
     }
 }
 
+// tiled mapping: wave (wi >> 6) renders one tile_w x tile_h tile of its rows, lanes row-major inside the tile
+__device__ __forceinline__ bool work_to_xy(const RtwRenderParams& p, int wi, int& x, int& y)
+{
+    const int wt = wi >> 6, l = wi & 63;
+    int band = (int)(((float)wt + 0.5f) / (float)p.tiles_per_row);
+    if (band * p.tiles_per_row > wt) band--;
+    if ((band + 1) * p.tiles_per_row <= wt) band++;
+    const int tx = wt - band * p.tiles_per_row;
+    const int vr = band * p.tile_h + (l >> p.tile_shift);
+    x = tx * p.tile_w + (l & (p.tile_w - 1));
+    if (p.world <= 1) y = p.row0 + vr;
+    else { const int j = vr / p.task_rows, r = vr - j * p.task_rows; y = (j * p.world + p.rank) * p.task_rows + r; }
+    return vr < p.nrows && y < p.height;
+}
 __device__ __forceinline__ int work_to_pixel(const RtwRenderParams& p, int wi)
 {
-    if (p.tile_w != 0) {            // wave (wi >> 6) renders one tile_w x tile_h tile; lanes row-major inside the tile
-        const int wt = wi >> 6, l = wi & 63;
-        int band = (int)(((float)wt + 0.5f) / (float)p.tiles_per_row);
-        if (band * p.tiles_per_row > wt) band--;
-        if ((band + 1) * p.tiles_per_row <= wt) band++;
-        const int tx = wt - band * p.tiles_per_row;
-        const int vr = band * p.tile_h + (l >> p.tile_shift);
-        const int x = tx * p.tile_w + (l & (p.tile_w - 1));
-        int y;
-        if (p.world <= 1) y = p.row0 + vr;
-        else { const int j = vr / p.task_rows, r = vr - j * p.task_rows; y = (j * p.world + p.rank) * p.task_rows + r; }
-        return (vr < p.nrows && y < p.height) ? y * p.width + x : p.width * p.height;
+    if (p.tile_w != 0) {
+        int x, y;
+        return work_to_xy(p, wi, x, y) ? y * p.width + x : p.width * p.height;
     }
     if (p.world <= 1) return p.begin + wi;
     const int per_task = p.task_rows * p.width;
@@ -1443,7 +1485,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
             f3 L = mk(0, 0, 0);
             bool done = false;
             if (have_hit) {
-                const float4 r0 = pb.hitslot[(size_t)q * 2], r1 = pb.hitslot[(size_t)q * 2 + 1];
+                // round 0 of the bins + wave pipeline: its primary kernel files hit records under the path id, not the slot
+                const size_t rec = (round == 0 && p.wavefront == 2) ? (size_t)pid : (size_t)q;
+                const float4 r0 = pb.hitslot[rec * 2], r1 = pb.hitslot[rec * 2 + 1];
                 const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
                 if (hs < 0) { L = sky_color(ray.d.y); done = true; }
                 else {
@@ -1705,8 +1749,9 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     int resolve_blocks = grid < 1024 ? grid : 1024;
     if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
     if (p.wavefront == 2) {
-        if (stats) hipLaunchKernelGGL(primary_bins_kernel<true>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-        else hipLaunchKernelGGL(primary_bins_kernel<false>, dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        const int pgrid = grid < tune.wave_blocks * tune.primary_blocks_per_cu ? grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // persistent waves
+        if (stats) hipLaunchKernelGGL(primary_bins_kernel<true>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        else hipLaunchKernelGGL(primary_bins_kernel<false>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     } else if (p.packets) {
         if (stats) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);

@@ -121,6 +121,9 @@ struct RtwRenderParams {
     int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
     int32_t pad_params;
     const struct RtwBinsDev* bins;  // [n_shapes] or null
+    const uint32_t* tile_order;     // full-frame launches: the order in which the primary kernel takes the tiles (null = as numbered)
+    const float* cam_dx;            // tiled mapping: dx of every pixel column / dy of every pixel row (Src/RayTracerProgram.cpp:141-142),
+    const float* cam_dy;            // computed once on the host with the same float operations
 };
 
 // screen-space bins of one shape for one (width, height, tile shape): CSR over the bins, entries = node index of a leaf, ascending

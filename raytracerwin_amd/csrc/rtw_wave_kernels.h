@@ -231,22 +231,34 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     __shared__ float thr[256];
     thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
     __syncthreads();
-    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = p.width * p.height;
-    const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
-    const bool live = pixel < npix;
-    // the wave's bin: all its pixels lie in one tile of the screen's bin grid (tile rows never straddle a bin row)
-    const unsigned long long live_mask = __ballot(live);
-    int bin = 0;
-    if (live_mask != 0ull) {
-        const int first_pixel = __builtin_amdgcn_readlane(pixel, __ffsll((long long)live_mask) - 1);
-        const int fy = first_pixel / p.width, fx = first_pixel - fy * p.width;
-        bin = (fy >> (6 - p.tile_shift)) * p.tiles_per_row + (fx >> p.tile_shift);      // tile_w = 1 << tile_shift, tile_h = 64 / tile_w
-    }
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     const uint32_t phase = table_phase(p.seed);
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
+    // persistent waves: the grid holds a few blocks per CU and every wave takes tiles in turn, so that the gamma table
+    // above and the launch of a wave are paid once per many tiles, not once per 64 pixels
+    const int n_tiles = p.count >> 6;
+    const int wave0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+  for (int wk = wave0; wk < n_tiles; wk += nwaves) {
+    // tiles with the longest bin lists first (their waves take longest; the many empty tiles then fill the tail)
+    const int wt = p.tile_order ? (int)cldu(p.tile_order, wk) : wk;
+    const int wi = wt * 64 + lane_id();
+    int px = 0, py = 0;
+    const bool live = work_to_xy(p, wi, px, py);
+    if (!live) { px = 0; py = 0; }
+    const int pixel = live ? py * p.width + px : npix;
+    // the accumulator entry is needed at the very end: ask for it now
+    float4 acc_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && !p.preview && !(p.pad_params & 2)) acc_prev = accum[pixel];
+    // the wave's bin: all its pixels lie in one tile of the screen's bin grid (tile rows never straddle a bin row)
+    const unsigned long long live_mask = __ballot(live);
+    int bin = 0;
+    if (live_mask != 0ull) {
+        const int first = __ffsll((long long)live_mask) - 1;
+        const int fy = __builtin_amdgcn_readlane(py, first), fx = __builtin_amdgcn_readlane(px, first);
+        bin = (fy >> (6 - p.tile_shift)) * p.tiles_per_row + (fx >> p.tile_shift);      // tile_w = 1 << tile_shift, tile_h = 64 / tile_w
+    }
     // Can any sample of this wave's pixels hit anything?  Only if a shape has leaves in the tile's bin (or has no bins).
     // Then every sample's colour is kept (resolve_kernel sums a pending pixel's samples in order); else nothing is kept.
     bool near_wave = false;
@@ -255,15 +267,17 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);
     }
     f3 csum = mk(0, 0, 0);                                   // s[0] + s[1] + ... in sample order, as the reference adds them
-    bool pending = false;
+    uint32_t queued = 0u;
     for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
         PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)p.pass_index, (uint32_t)i);
-        const Ray ray = camera_ray(p.width, p.height, live ? pixel : 0, i, rng);
+        const Ray ray = camera_ray_xy(p, px, py, i, rng);
         if (STATS && live) ct.cams++;
         f3 si = mk(0, 0, 0);
         bool queue_it = false;
         float4 hr0 = make_float4(0.f, 0.f, 0.f, 0.f), hr1 = hr0;
-        if (p.max_bounce != 0) {                             // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+        if (p.max_bounce != 0 && ((!near_wave && !STATS) || (p.pad_params & 4))) {     // no leaf of any shape can be met from this tile: every sample sees the sky
+            if (live) si = sky_color(ray.d.y);
+        } else if (p.max_bounce != 0) {                      // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
             // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
             int hit_shape = -1, hit_slot = -1;
             f3 hit_pos = mk(0, 0, 0);
@@ -289,24 +303,38 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
                     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
                     const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
                     const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
-                    for (int e = e0; e < e1; e++) {
-                        const int node = __builtin_amdgcn_readfirstlane((int)cldu(bent, e));
-                        const float4 lo = cld4(nd4, 2 * node), hi = cld4(nd4, 2 * node + 1);
-                        const int leaf = __float_as_int(hi.w);
-                        const float x1 = (lo.x - ray.o.x) * ix, x2 = (hi.x - ray.o.x) * ix;
-                        const float y1 = (lo.y - ray.o.y) * iy, y2 = (hi.y - ray.o.y) * iy;
-                        const float z1 = (lo.z - ray.o.z) * iz, z2 = (hi.z - ray.o.z) * iz;
-                        const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
-                        const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-                        bool hit = active && (tmax > tmin);
-                        if (prune) hit = hit && !(tmin > cur + (eps_t + 1.0e-4f * cur)) && !(tmax < -eps_t);
-                        if (STATS) ct.boxes += active ? 1u : 0u;
-                        if (__ballot(hit) == 0ull) continue;
-                        const float4 a = cld4(tr4, 4 * leaf), b = cld4(tr4, 4 * leaf + 1), c = cld4(tr4, 4 * leaf + 2), d = cld4(tr4, 4 * leaf + 3);
-                        if (hit) {
-                            if (STATS) ct.tris++;
-                            f3 cp; float dist;
-                            if (triangle_test(ray, cur, a, b, c, d.x, cp, dist)) { cur = dist; pos = cp; slot = leaf; any = true; }
+                    const int lane = lane_id();
+                    // 64 entries at a time: lane j fetches entry j's leaf box and triangle record (all loads in flight together),
+                    // then the wave goes through the entries in order and every lane tests its own ray against the broadcast record
+                    for (int ec = e0; ec < e1; ec += 64) {
+                        const int cnt = e1 - ec < 64 ? e1 - ec : 64;
+                        const int mnode = lane < cnt ? (int)bent[ec + lane] : 0;
+                        const float4 mlo = gld4(nd4, 2 * (size_t)mnode), mhi = gld4(nd4, 2 * (size_t)mnode + 1);
+                        const int mleaf = __float_as_int(mhi.w) < 0 ? 0 : __float_as_int(mhi.w);
+                        const float4 ta = gld4(tr4, 4 * (size_t)mleaf), tb = gld4(tr4, 4 * (size_t)mleaf + 1), tc = gld4(tr4, 4 * (size_t)mleaf + 2);
+                        const float td = gld4(tr4, 4 * (size_t)mleaf + 3).x;
+                        for (int j = 0; j < cnt; j++) {
+                            const float lox = readlane_f(mlo.x, j), loy = readlane_f(mlo.y, j), loz = readlane_f(mlo.z, j);
+                            const float hix = readlane_f(mhi.x, j), hiy = readlane_f(mhi.y, j), hiz = readlane_f(mhi.z, j);
+                            const float x1 = (lox - ray.o.x) * ix, x2 = (hix - ray.o.x) * ix;
+                            const float y1 = (loy - ray.o.y) * iy, y2 = (hiy - ray.o.y) * iy;
+                            const float z1 = (loz - ray.o.z) * iz, z2 = (hiz - ray.o.z) * iz;
+                            const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                            const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                            bool hit = active && (tmax > tmin);
+                            if (prune) hit = hit && !(tmin > cur + (eps_t + 1.0e-4f * cur)) && !(tmax < -eps_t);
+                            if (STATS) ct.boxes += active ? 1u : 0u;
+                            if (__ballot(hit) == 0ull) continue;
+                            const int leaf = __builtin_amdgcn_readlane(mleaf, j);
+                            const float4 a = make_float4(readlane_f(ta.x, j), readlane_f(ta.y, j), readlane_f(ta.z, j), readlane_f(ta.w, j));
+                            const float4 b = make_float4(readlane_f(tb.x, j), readlane_f(tb.y, j), readlane_f(tb.z, j), readlane_f(tb.w, j));
+                            const float4 c = make_float4(readlane_f(tc.x, j), readlane_f(tc.y, j), readlane_f(tc.z, j), readlane_f(tc.w, j));
+                            const float d1 = readlane_f(td, j);
+                            if (hit) {
+                                if (STATS) ct.tris++;
+                                f3 cp; float dist;
+                                if (triangle_test(ray, cur, a, b, c, d1, cp, dist)) { cur = dist; pos = cp; slot = leaf; any = true; }
+                            }
                         }
                     }
                 }
@@ -336,15 +364,44 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         }
         csum = csum + si;
         if (live && near_wave && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
-        pending = pending || queue_it;
-        const uint32_t at = wave_push_slot(pb.queue, &pb.counters[0], queue_it, (uint32_t)wi * 4u + (uint32_t)i);
-        if (at != 0xFFFFFFFFu && at < pb.capacity) { pb.hitslot[(size_t)at * 2] = hr0; pb.hitslot[(size_t)at * 2 + 1] = hr1; }
+        if (queue_it) {                                      // the hit record waits under the path id; the queue entry follows below
+            queued |= 1u << i;
+            pb.hitrec[((size_t)wi * 4 + i) * 2] = hr0; pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = hr1;
+        }
+    }
+    // ONE atomic per wave for both lists (the two counters are one 64-bit word): the queue gets an entry per queued sample,
+    // the pending list one per pixel with a queued sample
+    const bool pending = queued != 0u;
+    {
+        const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
+                                 m3 = __ballot((queued & 8u) != 0u), mp = __ballot(pending);
+        if (mp != 0ull && !(p.pad_params & 8)) {
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
+            unsigned long long base = 0ull;
+            if (lane_id() == 0)
+                base = atomicAdd(reinterpret_cast<unsigned long long*>(pb.counters), (unsigned long long)(c0 + c1 + c2 + c3) | ((unsigned long long)__popcll(mp) << 32));
+            const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            const uint32_t pbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+            if (queued & 1u) pb.queue[qb + (uint32_t)mbcnt(m0)] = (uint32_t)wi * 4u;
+            if (queued & 2u) pb.queue[qb + c0 + (uint32_t)mbcnt(m1)] = (uint32_t)wi * 4u + 1u;
+            if (queued & 4u) pb.queue[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = (uint32_t)wi * 4u + 2u;
+            if (queued & 8u) pb.queue[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = (uint32_t)wi * 4u + 3u;
+            if (pending) pb.pend[pbase + (uint32_t)mbcnt(mp)] = (uint32_t)wi;
+        }
     }
     if (live && !pending) {
-        const f3 c = csum / (float)p.sub_samples;
-        resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
+        const f3 c = p.sub_samples == 1 ? csum : csum / (float)p.sub_samples;     // x / 1.0f == x
+        if (p.preview) {
+            argb[pixel] = pack_pixel(thr, c);
+        } else {                                             // AccumulatePixel::AddPixel + GetGammaSpacePixel (resolve_pixel, with the entry loaded above)
+            const f3 sum = mk(acc_prev.x, acc_prev.y, acc_prev.z) + c;
+            const int n = __float_as_int(acc_prev.w) + 1;
+            if (!(p.pad_params & 2)) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+            if (p.pad_params & 1) argb[pixel] = __float_as_uint(sum.x);
+            else argb[pixel] = pack_pixel(thr, n == 1 ? sum : sum / (float)n);
+        }
     }
-    wave_push(pb.pend, &pb.counters[1], pending, (uint32_t)wi);
+  }
     if (STATS) flush_counters(sc, ct);
 }
 
@@ -443,7 +500,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
             ray = camera_ray(p.width, p.height, pixel, sub, rng);
             depth = p.max_bounce;
             have_hit = !(qe >> 31);                      // else: an untame camera ray, its first segment is traced like any other
-            if (have_hit) { r0 = pb.hitslot[(size_t)q * 2]; r1 = pb.hitslot[(size_t)q * 2 + 1]; }
+            if (have_hit) { r0 = pb.hitrec[(size_t)pid * 2]; r1 = pb.hitrec[(size_t)pid * 2 + 1]; }     // the primary kernel files hit records under the path id
         }
         LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
         for (;;) {

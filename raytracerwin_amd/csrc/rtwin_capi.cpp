@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -76,6 +77,8 @@ struct rtw_context {
     int known_rounds[32];               // wavefront: trace-list lengths of that pass
     int cu_count = 256;
     int wave_stage = -1;                // pipeline 3: LDS staging of shape 0 in the path kernel (-1 = as much as fits, 0..3 = fixed)
+    int debug_primary = 0;              // timing experiments only (wrong images): 1 no gamma, 2 no accumulator traffic, 4 no bins loop
+    int primary_blocks_per_cu = 64;     // pipeline 3: persistent primary kernel, blocks of 256 threads per CU
     int wave_fused = 0;                 // pipeline 3: 1 = one kernel carries the paths to their end, 0 = a launch per bounce
     int wave_paths = 0;                 // pipeline 3: paths per wave of the path kernel (0 = chosen from the queue length)
     int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
@@ -92,7 +95,7 @@ struct rtw_scene {
     RtwSceneDev* d_scene = nullptr;
     std::vector<void*> allocs;
     // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
-    struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; };
+    struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; const float* d_dx; const float* d_dy; const uint32_t* d_order; };
     std::vector<BinSet> bin_sets;
 };
 
@@ -203,6 +206,12 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "wave_stage") == 0) {
         if (value < -1 || value > 3) return fail(RTW_ERR_INVALID, "wave_stage must be -1 (automatic) or 0..3");
         ctx->wave_stage = value;
+        return RTW_OK;
+    }
+    if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
+    if (std::strcmp(name, "primary_blocks_per_cu") == 0) {
+        if (value < 1 || value > 64) return fail(RTW_ERR_INVALID, "primary_blocks_per_cu must be 1..64");
+        ctx->primary_blocks_per_cu = value;
         return RTW_OK;
     }
     if (std::strcmp(name, "wave_fused") == 0) {
@@ -661,23 +670,38 @@ int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb)
 }
 
 // Bins of every shape of the scene for one frame size and bin shape, built and uploaded on first use.
-static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bin_h, RtwBinsDev** out)
+static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bin_h, const rtw_scene::BinSet** out)
 {
     for (const rtw_scene::BinSet& b : scene->bin_sets)
-        if (b.width == width && b.height == height && b.bin_w == bin_w && b.bin_h == bin_h) { *out = b.d_bins; return RTW_OK; }
+        if (b.width == width && b.height == height && b.bin_w == bin_w && b.bin_h == bin_h) { *out = &b; return RTW_OK; }
     std::vector<RtwBinsDev> h(scene->meshes.size());
+    const size_t n_bins = (size_t)(width / bin_w) * (size_t)(height / bin_h);
+    std::vector<uint32_t> weight(n_bins, 0u);
     for (size_t s = 0; s < scene->meshes.size(); s++) {
         std::vector<uint32_t> off, ent;
         h[s].off = nullptr; h[s].ent = nullptr;
-        if (!rtw::build_bins(*scene->meshes[s], width, height, bin_w, bin_h, off, ent)) continue;
+        if (!rtw::build_bins(*scene->meshes[s], width, height, bin_w, bin_h, off, ent)) { for (auto& w : weight) w += 1000u; continue; }
+        for (size_t b = 0; b < n_bins; b++) weight[b] += off[b + 1] - off[b];
         int rc;
         if ((rc = upload(scene, off, &h[s].off)) != RTW_OK) return rc;
         if ((rc = upload(scene, ent, &h[s].ent)) != RTW_OK) return rc;
     }
-    const RtwBinsDev* d = nullptr;
+    // the camera's per-column dx and per-row dy, as ThreadWorker_Render computes them for every pixel (Src/RayTracerProgram.cpp:141-142)
+    std::vector<float> dx((size_t)width), dy((size_t)height);
+    const float aspect = (float)width / (float)height;
+    for (int x = 0; x < width; x++) dx[(size_t)x] = -(float)(x - width / 2) / (width * 2) * aspect;
+    for (int y = 0; y < height; y++) dy[(size_t)y] = -(float)(y - height / 2) / (height * 2);
+    // bins in order of decreasing list length (stable): the primary kernel of a full-frame launch takes its tiles in this order
+    std::vector<uint32_t> order(n_bins);
+    for (size_t b = 0; b < n_bins; b++) order[b] = (uint32_t)b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    const RtwBinsDev* d = nullptr; const float* ddx = nullptr; const float* ddy = nullptr; const uint32_t* dord = nullptr;
     int rc = upload(scene, h, &d); if (rc != RTW_OK) return rc;
-    scene->bin_sets.push_back({ width, height, bin_w, bin_h, const_cast<RtwBinsDev*>(d) });
-    *out = const_cast<RtwBinsDev*>(d);
+    if ((rc = upload(scene, order, &dord)) != RTW_OK) return rc;
+    if ((rc = upload(scene, dx, &ddx)) != RTW_OK) return rc;
+    if ((rc = upload(scene, dy, &ddy)) != RTW_OK) return rc;
+    scene->bin_sets.push_back({ width, height, bin_w, bin_h, const_cast<RtwBinsDev*>(d), ddx, ddy, dord });
+    *out = &scene->bin_sets.back();
     return RTW_OK;
 }
 
@@ -729,10 +753,11 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     int pipeline = scene->ctx->pipeline;
     if (pipeline == 3) {
         RtwRenderParams tiled = p;
-        RtwBinsDev* d_bins = nullptr;
+        const rtw_scene::BinSet* bs = nullptr;
         if (scene->traversal != 0 && scene->ctx->packets != 0 && choose_tiles(tiled) &&
-            scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &d_bins) == RTW_OK) {
-            p = tiled; p.bins = d_bins;
+            scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &bs) == RTW_OK) {
+            p = tiled; p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
+            p.tile_order = (p.world <= 1 && p.row0 == 0 && p.nrows == p.height) ? bs->d_order : nullptr;
         } else {
             pipeline = 2;
         }
@@ -766,7 +791,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
         p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
         p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
-        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused;
+        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
             const rtw::HostMesh& m0 = *scene->meshes[0];
@@ -789,6 +814,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
                 if (B > 32) B = 32;
             }
             p.wave_paths = B;
+            p.pad_params = cx->debug_primary;
         }
         tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
         tune.path_variant = cx->path_variant;
