@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--prune", type=int, default=1)
-    ap.add_argument("--pipeline", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=3)
     ap.add_argument("--traversal", type=int, default=1)
     ap.add_argument("--packets", type=int, default=1)
     ap.add_argument("--path-lanes", type=int, default=16)
@@ -299,9 +299,10 @@ def main():
             "rays_per_frame": rays_total / K,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": "render pass = primary_kernel + path_kernel + resolve_kernel (one rtw_render_tasks call)" if args.pipeline >= 1 else "render_kernel",
+                         "kernel": ("render pass = primary_bins_kernel + per-bounce shade_kernel / trace_wave_kernel rounds + resolve_kernel (one rtw_render_tasks call)" if args.pipeline == 3
+                                    else "render pass = primary_kernel + path kernels + resolve_kernel (one rtw_render_tasks call)" if args.pipeline >= 1 else "render_kernel"),
                          "kernel_ms": pass_ms,
-                         "kernels_ms": dict(zip(("primary_kernel", "path_kernel", "resolve_kernel"), kernel_parts)) if kernel_parts else None,
+                         "kernels_ms": dict(zip(("primary", "bounce_rounds", "resolve"), kernel_parts)) if kernel_parts else None,
                          "loop_ms_per_step_hip_events": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "executed_bytes_per_launch": run_bytes,

@@ -169,6 +169,13 @@ int rtw_render_range(rtw_scene* scene, rtw_framebuffer* fb, int begin, int end, 
  * identical for every world size. */
 int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
                      int max_bounce, int use_base_color, int pass_index, int sub_samples, uint32_t seed);
+/* UpdateBitmapPixels' sample loop (Src/RayTracerProgram.cpp:317-361): n_passes accumulated passes
+ * first_pass .. first_pass + n_passes - 1 over this rank's tasks, as rtw_render_tasks would render
+ * them one by one (same images).  After the first passes the library replays one captured launch
+ * graph per pass, so a long progressive render is not bound by launch overhead. */
+int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
+                      int max_bounce, int use_base_color, int first_pass, int n_passes,
+                      int sub_samples, uint32_t seed);
 
 /* work counters of launches since the last reset (only counted while enabled) */
 int rtw_stats_enable(rtw_context* ctx, int enabled);

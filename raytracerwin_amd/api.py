@@ -411,6 +411,16 @@ class RayTracerScene:
         _check(library().rtw_render_tasks(self.h, fb.h, int(task_rows), int(rank), int(world), int(MaxBounceCount),
                                           int(opt.UseBaseColor), int(pass_index), int(sub_samples), C.c_uint32(seed)))
 
+    def render_passes(self, fb, task_rows, rank, world, MaxBounceCount, InOption=None, first_pass=0, n_passes=1,
+                      sub_samples=4, seed=12345):
+        """UpdateBitmapPixels' sample loop (Src/RayTracerProgram.cpp:317-361): n_passes accumulated passes, same images
+        as render_tasks pass by pass; after the first passes one captured launch graph is replayed per pass."""
+        self.commit()
+        opt = InOption or RenderOption()
+        _check(library().rtw_render_passes(self.h, fb.h, int(task_rows), int(rank), int(world), int(MaxBounceCount),
+                                           int(opt.UseBaseColor), int(first_pass), int(n_passes), int(sub_samples),
+                                           C.c_uint32(seed)))
+
     def close(self):
         if getattr(self, "h", None):
             library().rtw_scene_destroy(self.h)

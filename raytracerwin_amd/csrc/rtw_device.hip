@@ -1177,6 +1177,9 @@ __device__ __forceinline__ int work_to_pixel(const RtwRenderParams& p, int wi)
     return (j * p.world + p.rank) * per_task + r;
 }
 
+// the pass index: a launch parameter, or (replayed launch graphs) a device word that resolve_kernel advances
+__device__ __forceinline__ int pass_of(const RtwRenderParams& p) { return p.pass_ptr ? *p.pass_ptr : p.pass_index; }
+
 // ---- kernels -----------------------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
@@ -1196,7 +1199,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
         LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi;
         f3 c = mk(0, 0, 0);
         for (int i = 0; i < p.sub_samples; i++) {
-            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)i);
             const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
             if (STATS) ct.cams++;
             c = c + trace_path<STATS, 1, false>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
@@ -1299,7 +1302,7 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
     for (int i = 0; i < 4; i++) {                            // wave-uniform loop: the packet walk needs the whole wave
         s[i] = mk(0, 0, 0);
         if (i >= p.sub_samples) continue;
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)p.pass_index, (uint32_t)i);
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)pass_of(p), (uint32_t)i);
         const Ray ray = camera_ray(p.width, p.height, live ? pixel : 0, i, rng);
         if (STATS && live) ct.cams++;
         if (p.max_bounce == 0) continue;                     // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
@@ -1406,7 +1409,7 @@ __global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __res
         const uint32_t pid = qe & 0x7FFFFFFFu;
         const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
         const int pixel = work_to_pixel(p, wi);
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)sub);
         const Ray ray = camera_ray(p.width, p.height, pixel, sub, rng);
         f3 L;
         if (p.packets && !(qe >> 31)) {
@@ -1470,7 +1473,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
             PathRng rng; Ray ray; int depth, nlev;
             bool have_hit = true;
             if (round == 0) {
-                rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
+                rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)sub);
                 ray = camera_ray(p.width, p.height, pixel, sub, rng);
                 depth = p.max_bounce; nlev = 0;
                 if (qe >> 31) have_hit = false;                            // untame camera ray: its first segment is traced like any other
@@ -1478,7 +1481,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
                 const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1], s2 = pb.state[(size_t)q * 3 + 2];
                 ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
                 rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
-                rng.table_base = (((uint64_t)p.pass_index * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
+                rng.table_base = (((uint64_t)pass_of(p) * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
                 nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
             }
             LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
@@ -1620,6 +1623,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restr
         c = c / (float)p.sub_samples;
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
     }
+    if (p.pass_ptr && blockIdx.x == 0 && threadIdx.x == 0) *p.pass_ptr += 1;       // last kernel of the pass; nothing here reads the pass index
 }
 
 template <bool STATS>

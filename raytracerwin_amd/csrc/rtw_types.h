@@ -121,6 +121,7 @@ struct RtwRenderParams {
     int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
     int32_t pad_params;
     const struct RtwBinsDev* bins;  // [n_shapes] or null
+    int32_t* pass_ptr;              // not null: the pass index lives on the device (replayed launch graphs); resolve_kernel adds 1 to it
     const uint32_t* tile_order;     // full-frame launches: the order in which the primary kernel takes the tiles (null = as numbered)
     const float* cam_dx;            // tiled mapping: dx of every pixel column / dy of every pixel row (Src/RayTracerProgram.cpp:141-142),
     const float* cam_dy;            // computed once on the host with the same float operations

@@ -40,12 +40,13 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct FlatRay { f3 o; float ix, iy, iz, eps_t; };
+struct FlatRay { f3 o; float ix, iy, iz, eps_t; bool skx, sky, skz; };   // sk*: axis skipped by the reference's test (|d| < FLT_EPSILON)
 
 // reference box test of a tame ray (RRay::TestIntersectionWithAabb, Src/RRay.cpp:89-136) on entry idx of a flat
 // level, plus the conservative segment clip when `prune`
-// LDSB: the level's arrays were staged in LDS by the block (same layout)
-template <bool LDSB>
+// LDSB: the level's arrays were staged in LDS by the block (same layout).  EXACT: the ray is not "tame" (a direction
+// component below FLT_EPSILON, NaN, ...): the reference's test as written (skipped axes, Math::Min/Max), no clip.
+template <bool LDSB, bool EXACT>
 __device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pad, int idx, const FlatRay& fr, bool prune, float far_t)
 {
     float mnx, mny, mnz, mxx, mxy, mxz;
@@ -59,6 +60,13 @@ __device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pa
     const float x1 = (mnx - fr.o.x) * fr.ix, x2 = (mxx - fr.o.x) * fr.ix;
     const float y1 = (mny - fr.o.y) * fr.iy, y2 = (mxy - fr.o.y) * fr.iy;
     const float z1 = (mnz - fr.o.z) * fr.iz, z2 = (mxz - fr.o.z) * fr.iz;
+    if (EXACT) {
+        float tmin = -FLT_MAX, tmax = FLT_MAX;
+        if (!fr.skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
+        if (!fr.sky) { tmin = ref_max(tmin, ref_min(y1, y2)); tmax = ref_min(tmax, ref_max(y1, y2)); }
+        if (!fr.skz) { tmin = ref_max(tmin, ref_min(z1, z2)); tmax = ref_min(tmax, ref_max(z1, z2)); }
+        return tmax > tmin;
+    }
     const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
     const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
     bool h = tmax > tmin;
@@ -115,7 +123,7 @@ __device__ __forceinline__ void wave_triangles(const float4* __restrict__ tr4, c
 
 // KdTree::TestRayIntersection for ONE tame ray held identically by all 64 lanes.  Depth-first over the three flat
 // levels, four entries (64 children) per step, so the leaves come out in ascending slot order = preorder.
-template <bool STATS, int STAGE>
+template <bool STATS, int STAGE, bool EXACT>
 __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __restrict__ lds, const Ray& r, const FlatRay& fr, bool prune,
                                                float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
 {
@@ -128,7 +136,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
         float far_t = cur_dist + (fr.eps_t + 1.0e-4f * cur_dist);
         const int i2 = t0 + lane;
         const bool v2 = i2 < n2;
-        const bool h2 = v2 && flat_box_hit<(STAGE >= 1)>(src.lvl[2], src.pad[2], i2, fr, prune, far_t);
+        const bool h2 = v2 && flat_box_hit<(STAGE >= 1), EXACT>(src.lvl[2], src.pad[2], i2, fr, prune, far_t);
         if (STATS) ct.boxes += v2 ? 1u : 0u;
         const unsigned long long m2 = __ballot(h2);
         if (m2 == 0ull) continue;
@@ -140,7 +148,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
             const int g = g2 + lane;
             const int i1 = (g < c2 ? (int)lldu(l2, g >> 4) : 0) * 16 + (g & 15);
             const bool v1 = g < c2 && i1 < n1;
-            const bool h1 = v1 && flat_box_hit<(STAGE >= 1)>(src.lvl[1], src.pad[1], i1, fr, prune, far_t);
+            const bool h1 = v1 && flat_box_hit<(STAGE >= 1), EXACT>(src.lvl[1], src.pad[1], i1, fr, prune, far_t);
             if (STATS) ct.boxes += v1 ? 1u : 0u;
             const unsigned long long m1 = __ballot(h1);
             if (m1 == 0ull) continue;
@@ -152,7 +160,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
                 const int gg = g1 + lane;
                 const int i0 = (gg < c1 ? (int)lldu(l1, gg >> 4) : 0) * 16 + (gg & 15);
                 const bool v0 = gg < c1 && i0 < n0;
-                const bool h0 = v0 && flat_box_hit<(STAGE >= 2)>(src.lvl[0], src.pad[0], i0, fr, prune, far_t);
+                const bool h0 = v0 && flat_box_hit<(STAGE >= 2), EXACT>(src.lvl[0], src.pad[0], i0, fr, prune, far_t);
                 if (STATS) ct.boxes += v0 ? 1u : 0u;
                 const unsigned long long m0 = __ballot(h0);
                 if (m0 == 0ull) continue;
@@ -188,8 +196,10 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
     const bool one = lane_id() == 0;
     if (STATS && one) ct.rays++;
     const bool tame = ray_is_tame(ray);
-    FlatRay fr;             // the three reciprocals of a tame ray, shared by the shape-bound test and the walk
-    fr.o = ray.o; fr.ix = 1.0f / ray.d.x; fr.iy = 1.0f / ray.d.y; fr.iz = 1.0f / ray.d.z;
+    FlatRay fr;             // the ray's reciprocals (0 on an axis the reference's test skips), shared by the bound test and the walk
+    fr.o = ray.o;
+    fr.skx = near_zero(ray.d.x); fr.sky = near_zero(ray.d.y); fr.skz = near_zero(ray.d.z);
+    fr.ix = (!tame && fr.skx) ? 0.0f : 1.0f / ray.d.x; fr.iy = (!tame && fr.sky) ? 0.0f : 1.0f / ray.d.y; fr.iz = (!tame && fr.skz) ? 0.0f : 1.0f / ray.d.z;
     fr.eps_t = 2.0e-5f * fmaxf(fabsf(fr.ix), fmaxf(fabsf(fr.iy), fabsf(fr.iz)));
     for (int s = 0; s < n_shapes; s++) {
         const FlatSrc g = (s == 0) ? shape0 : flat_src_of(sc->shapes[s]);
@@ -209,10 +219,14 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
         if (!in_bound) continue;
         float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
         bool any;
-        if (tame && g.n[0] > 0) {
-            if (STAGE > 0 && s == 0) any = wave_walk_flat<STATS, STAGE>(g, lds, ray, fr, prune, cur, pos, slot, ct);
-            else any = wave_walk_flat<STATS, 0>(g, lds, ray, fr, prune, cur, pos, slot, ct);
-        } else {                    // a direction component below FLT_EPSILON, NaN, ...: the reference's own walk, all lanes alike
+        if (g.n[0] > 0) {
+            if (tame) {
+                if (STAGE > 0 && s == 0) any = wave_walk_flat<STATS, STAGE, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
+                else any = wave_walk_flat<STATS, 0, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
+            } else {                // rare (a direction component below FLT_EPSILON, NaN, ...): same walk, the reference's test as written
+                any = wave_walk_flat<STATS, 0, true>(flat_src_of(sc->shapes[s]), lds, ray, fr, false, cur, pos, slot, ct);
+            }
+        } else {                    // a shape without a flat hierarchy: the reference's own walk, all lanes alike
             const RtwShapeDev& sh = sc->shapes[s];
             Counters walk = { 0, 0, 0, 0, 0, 0 };
             if (tame) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, prune, cur, pos, slot, walk);
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     f3 csum = mk(0, 0, 0);                                   // s[0] + s[1] + ... in sample order, as the reference adds them
     uint32_t queued = 0u;
     for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)p.pass_index, (uint32_t)i);
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)pass_of(p), (uint32_t)i);
         const Ray ray = camera_ray_xy(p, px, py, i, rng);
         if (STATS && live) ct.cams++;
         f3 si = mk(0, 0, 0);
@@ -284,6 +298,10 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
             float seg = ray.dist;
             if (STATS && live) ct.rays++;
             const bool tame = ray_is_tame(ray);
+            // a handful of rays per frame are not tame (a direction component below FLT_EPSILON at the image's centre column / row):
+            // they go through the same lists with the reference's test as written (skipped axes); only such waves pay for it
+            const bool any_untame = __ballot(live && !tame) != 0ull;
+            const bool skx = near_zero(ray.d.x), sky = near_zero(ray.d.y), skz = near_zero(ray.d.z);
             for (int k = 0; k < n_shapes; k++) {
                 const RtwShapeDev& sh = sc->shapes[k];
                 float t0, t1;
@@ -295,13 +313,18 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
                 const uint32_t* __restrict__ boff = p.bins[k].off;
                 if (boff == nullptr) {                       // no bins for this shape: packet walk of its tree
                     any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
+                    if (any_untame) {
+                        const bool a2 = packet_walk<STATS, true>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && !tame, false, cur, pos, slot, ct);
+                        any = any || a2;
+                    }
                 } else {
                     const bool active = inbox && tame;
+                    const bool active_exact = inbox && !tame;
                     const uint32_t* __restrict__ bent = p.bins[k].ent;
                     const int e0 = (int)cldu(boff, bin), e1 = (int)cldu(boff, bin + 1);
                     const float4* nd4 = reinterpret_cast<const float4*>(sh.nodes);
                     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
-                    const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+                    const float ix = (!tame && skx) ? 0.0f : 1.0f / ray.d.x, iy = (!tame && sky) ? 0.0f : 1.0f / ray.d.y, iz = (!tame && skz) ? 0.0f : 1.0f / ray.d.z;
                     const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
                     const int lane = lane_id();
                     // 64 entries at a time: lane j fetches entry j's leaf box and triangle record (all loads in flight together),
@@ -323,7 +346,14 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
                             const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
                             bool hit = active && (tmax > tmin);
                             if (prune) hit = hit && !(tmin > cur + (eps_t + 1.0e-4f * cur)) && !(tmax < -eps_t);
-                            if (STATS) ct.boxes += active ? 1u : 0u;
+                            if (any_untame) {                // wave-uniform: RRay::TestIntersectionWithAabb as written for the lanes that need it
+                                float emin = -FLT_MAX, emax = FLT_MAX;
+                                if (!skx) { emin = ref_max(emin, ref_min(x1, x2)); emax = ref_min(emax, ref_max(x1, x2)); }
+                                if (!sky) { emin = ref_max(emin, ref_min(y1, y2)); emax = ref_min(emax, ref_max(y1, y2)); }
+                                if (!skz) { emin = ref_max(emin, ref_min(z1, z2)); emax = ref_min(emax, ref_max(z1, z2)); }
+                                if (active_exact) hit = emax > emin;
+                            }
+                            if (STATS) ct.boxes += (active || active_exact) ? 1u : 0u;
                             if (__ballot(hit) == 0ull) continue;
                             const int leaf = __builtin_amdgcn_readlane(mleaf, j);
                             const float4 a = make_float4(readlane_f(ta.x, j), readlane_f(ta.y, j), readlane_f(ta.z, j), readlane_f(ta.w, j));
@@ -339,18 +369,6 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
                     }
                 }
                 if (any) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
-            }
-            if (live && !tame) {    // a handful per frame (a direction component below FLT_EPSILON): the reference's own walk, lane by lane
-                hit_shape = -1; seg = ray.dist;
-                for (int k = 0; k < n_shapes; k++) {
-                    const RtwShapeDev& sh = sc->shapes[k];
-                    float t0, t1;
-                    if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
-                    float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
-                    Counters walk = { 0, 0, 0, 0, 0, 0 };
-                    if (tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, false, cur, pos, slot, walk)) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
-                    if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
-                }
             }
             if (live) {
                 if (hit_shape < 0) {
@@ -496,7 +514,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
             pid = qe & 0x7FFFFFFFu;
             const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
             const int pixel = work_to_pixel(p, wi);
-            rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)sub);
+            rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)sub);
             ray = camera_ray(p.width, p.height, pixel, sub, rng);
             depth = p.max_bounce;
             have_hit = !(qe >> 31);                      // else: an untame camera ray, its first segment is traced like any other

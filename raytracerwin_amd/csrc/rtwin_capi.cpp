@@ -77,6 +77,21 @@ struct rtw_context {
     int known_rounds[32];               // wavefront: trace-list lengths of that pass
     int cu_count = 256;
     int wave_stage = -1;                // pipeline 3: LDS staging of shape 0 in the path kernel (-1 = as much as fits, 0..3 = fixed)
+    // a whole pass captured as a launch graph and replayed with the pass index on the device (rtw_render_passes)
+    struct PassGraph {
+        bool valid = false;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        const void* scene = nullptr; const void* fb = nullptr;
+        int task_rows = 0, rank = 0, world = 0, max_bounce = 0, preview = 0, sub_samples = 0;
+        uint32_t seed = 0;
+        int next_pass = -1;
+    } pass_graph;
+    int32_t* d_pass = nullptr;          // the replayed graph's pass index
+    int32_t* h_pass = nullptr;          // pinned staging word for d_pass
+    int hint_period = 1;                // the queue lengths are read back every hint_period-th pass
+    int hint_tick = 0;
+    int use_graph = 1;                  // rtw_render_passes: replay a captured pass (0 = launch every pass kernel by kernel)
     int debug_primary = 0;              // timing experiments only (wrong images): 1 no gamma, 2 no accumulator traffic, 4 no bins loop
     int primary_blocks_per_cu = 64;     // pipeline 3: persistent primary kernel, blocks of 256 threads per CU
     int wave_fused = 0;                 // pipeline 3: 1 = one kernel carries the paths to their end, 0 = a launch per bounce
@@ -163,6 +178,8 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_pass, 64, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&c->d_pass, 64));
     HIP_TRY(hipEventCreateWithFlags(&c->counters_event, hipEventDisableTiming));
     for (int i = 0; i < 64; i++) c->h_counters[i] = 0;
     for (int r = 0; r < 32; r++) c->known_rounds[r] = -1;
@@ -179,6 +196,10 @@ int rtw_context_destroy(rtw_context* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_unit); (void)hipFree(ctx->d_workspace); (void)hipFree(ctx->d_gamma); (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_stats);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pass_graph.exec) (void)hipGraphExecDestroy(ctx->pass_graph.exec);
+    if (ctx->pass_graph.graph) (void)hipGraphDestroy(ctx->pass_graph.graph);
+    if (ctx->h_pass) (void)hipHostFree(ctx->h_pass);
+    if (ctx->d_pass) (void)hipFree(ctx->d_pass);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->counters_event) (void)hipEventDestroy(ctx->counters_event);
     for (int i = 0; i < 4; i++) if (ctx->timing_events[i]) (void)hipEventDestroy(ctx->timing_events[i]);
@@ -209,6 +230,8 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         return RTW_OK;
     }
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
+    if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
+    if (std::strcmp(name, "use_graph") == 0) { ctx->use_graph = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "primary_blocks_per_cu") == 0) {
         if (value < 1 || value > 64) return fail(RTW_ERR_INVALID, "primary_blocks_per_cu must be 1..64");
         ctx->primary_blocks_per_cu = value;
@@ -740,7 +763,7 @@ static bool choose_tiles(RtwRenderParams& p)
 
 // ---- the hot path -------------------------------------------------------------------------------------------
 static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams& p, int max_bounce, int use_base_color,
-                         int pass_index, int sub_samples, uint32_t seed)
+                         int pass_index, int sub_samples, uint32_t seed, bool capturing = false, bool* used_bins_pipeline = nullptr)
 {
     if (fb->ctx != scene->ctx) return fail(RTW_ERR_INVALID, "scene and framebuffer belong to different contexts");
     if (max_bounce < 0 || max_bounce > RTW_MAX_BOUNCE) return fail(RTW_ERR_LIMIT, "max_bounce out of range");
@@ -758,6 +781,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
             scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &bs) == RTW_OK) {
             p = tiled; p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
             p.tile_order = (p.world <= 1 && p.row0 == 0 && p.nrows == p.height) ? bs->d_order : nullptr;
+            if (used_bins_pipeline) *used_bins_pipeline = true;
         } else {
             pipeline = 2;
         }
@@ -783,7 +807,8 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         // queue length of the previous pass with the same launch shape (a stale or missing value only costs speed)
         rtw_context* cx = scene->ctx;
         const long long shape = (long long)p.count * 64 + sub_samples;
-        if (cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
+        if (capturing) p.pass_ptr = cx->d_pass;              // the graph's kernels read the pass index from the device
+        if (!capturing && cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
             cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
             for (int r = 0; r < 32; r++) cx->known_rounds[r] = (int)cx->h_counters[4 + r];
         }
@@ -819,7 +844,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
         tune.path_variant = cx->path_variant;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
-        if (e == hipSuccess && !cx->counters_pending) {     // one copy in flight at a time; its value is used once it has landed
+        if (e == hipSuccess && !cx->counters_pending && !capturing && (cx->known_shape != shape || (cx->hint_tick++ % cx->hint_period) == 0)) {     // one copy in flight at a time; its value is used once it has landed
             const size_t off = rtw::pipeline_counters_offset(p.count, max_bounce);
             if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + off, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
                 hipEventRecord(cx->counters_event, cx->stream) == hipSuccess) {
@@ -865,6 +890,69 @@ int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int r
         p.count = (int)cnt;
     }
     return render_common(scene, fb, p, max_bounce, use_base_color, pass_index, sub_samples, seed);
+}
+
+// n_passes accumulated passes (UpdateBitmapPixels' sample loop, Src/RayTracerProgram.cpp:317-361) over this rank's tasks.
+// The first passes are launched kernel by kernel (they also tell the queue lengths the launches are sized from); once
+// those are known, ONE pass is captured as a launch graph whose kernels take the pass index from a device word that the
+// pass's last kernel advances, and every further pass is a single graph launch.
+int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world, int max_bounce, int use_base_color,
+                      int first_pass, int n_passes, int sub_samples, uint32_t seed)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
+    if (n_passes < 0 || first_pass < 0) return fail(RTW_ERR_INVALID, "bad pass range");
+    rtw_context* cx = scene->ctx;
+    rtw_context::PassGraph& g = cx->pass_graph;
+    for (int i = 0; i < n_passes; i++) {
+        const int pass = first_pass + i;
+        const bool same = g.valid && g.scene == scene && g.fb == fb && g.task_rows == task_rows && g.rank == rank && g.world == world &&
+                          g.max_bounce == max_bounce && g.preview == (use_base_color ? 1 : 0) && g.sub_samples == sub_samples && g.seed == seed;
+        if (same && cx->use_graph && !cx->stats_enabled && !cx->kernel_timing) {
+            if (g.next_pass != pass) {           // a new sequence: set the device's pass index
+                *cx->h_pass = pass;
+                HIP_TRY(hipMemcpyAsync(cx->d_pass, cx->h_pass, sizeof(int32_t), hipMemcpyHostToDevice, cx->stream));
+                HIP_TRY(hipStreamSynchronize(cx->stream));      // h_pass may be rewritten by the next call
+            }
+            HIP_TRY(hipGraphLaunch(g.exec, cx->stream));
+            g.next_pass = pass + 1;
+            continue;
+        }
+        rc = rtw_render_tasks(scene, fb, task_rows, rank, world, max_bounce, use_base_color, pass, sub_samples, seed);
+        if (rc != RTW_OK) return rc;
+        if (!cx->use_graph || cx->stats_enabled || cx->kernel_timing || cx->pipeline != 3 || i + 1 >= n_passes) continue;
+        // wait for this pass's queue lengths, then capture the next pass
+        if (cx->counters_pending) { HIP_TRY(hipEventSynchronize(cx->counters_event)); }
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+        g.valid = false;
+        // a dry run outside the capture settles everything that may allocate or synchronise (workspace, bins) and picks up the lengths
+        RtwRenderParams p; std::memset(&p, 0, sizeof p);
+        const int n_tasks = (fb->height + task_rows - 1) / task_rows;
+        const int mine = n_tasks > rank ? (n_tasks - rank + world - 1) / world : 0;
+        p.begin = 0; p.task_rows = task_rows; p.rank = rank; p.world = world;
+        p.count = world == 1 ? fb->width * fb->height : mine * task_rows * fb->width;
+        *cx->h_pass = pass + 1;
+        HIP_TRY(hipMemcpyAsync(cx->d_pass, cx->h_pass, sizeof(int32_t), hipMemcpyHostToDevice, cx->stream));
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+        if (cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
+            cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
+            for (int r = 0; r < 32; r++) cx->known_rounds[r] = (int)cx->h_counters[4 + r];
+        }
+        bool bins = false;
+        HIP_TRY(hipStreamBeginCapture(cx->stream, hipStreamCaptureModeRelaxed));
+        RtwRenderParams pc = p;
+        rc = render_common(scene, fb, pc, max_bounce, use_base_color, pass + 1, sub_samples, seed, true, &bins);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(cx->stream, &graph);
+        if (rc != RTW_OK || ce != hipSuccess || !graph || !bins) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); continue; }
+        hipGraphExec_t exec = nullptr;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) { (void)hipGraphDestroy(graph); (void)hipGetLastError(); continue; }
+        g.graph = graph; g.exec = exec; g.valid = true;
+        g.scene = scene; g.fb = fb; g.task_rows = task_rows; g.rank = rank; g.world = world; g.max_bounce = max_bounce;
+        g.preview = use_base_color ? 1 : 0; g.sub_samples = sub_samples; g.seed = seed; g.next_pass = pass + 1;
+    }
+    return RTW_OK;
 }
 
 // ---- stats ------------------------------------------------------------------------------------------------------
