@@ -129,6 +129,16 @@ int rtw_scene_set_prune(rtw_scene* scene, int enabled);
 int rtw_scene_set_traversal(rtw_scene* scene, int mode);
 /* 4-wide tree for inspection: returns the quad count; child4 as in rtw_types.h (leaf = -1 - original triangle) */
 int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int32_t* child4, int max_quads);
+/* The flat hierarchy over the leaves in preorder that the wave-per-ray walk uses: level 0 = each
+ * leaf's own box (KdNode::Bounds of the leaf, Src/KdTree.cpp:37-60), level 1 / 2 = unions of 16 /
+ * 256 consecutive leaves.  boxes6 = min.xyz, max.xyz per entry.  Returns the level's entry count. */
+int rtw_scene_mesh_flat(const rtw_scene* scene, int shape, int level, float* boxes6, int max_entries);
+/* Screen-space bins of the reference's fixed camera (Src/RayTracerProgram.cpp:133-165) for a
+ * width x height frame cut into bin_w x bin_h pixel bins: CSR offsets (bins + 1) and, per bin, the
+ * node indices (ascending) of the leaves a camera ray of the bin's pixels can meet.  counts2 =
+ * {number of offsets, number of entries}.  Returns 1, or 0 when this mesh gets no bins. */
+int rtw_scene_mesh_bins(const rtw_scene* scene, int shape, int width, int height, int bin_w, int bin_h,
+                        uint32_t* offsets, int64_t max_offsets, uint32_t* entries, int64_t max_entries, int64_t* counts2);
 
 /* ---- ray-level queries (parity surface) ---- */
 /* RayTracerScene::FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) for n rays.

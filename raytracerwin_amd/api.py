@@ -376,6 +376,30 @@ class RayTracerScene:
         _check(library().rtw_scene_mesh_quads(self.h, shape, _p(b), _p(c), n))
         return b, c
 
+    def mesh_flat(self, level, shape=0):
+        """boxes (n, 6) of one level of the flat leaf hierarchy (0 = leaves in preorder, 1 = groups of 16, 2 = groups of 256)"""
+        self.commit()
+        n = library().rtw_scene_mesh_flat(self.h, shape, int(level), None, 0)
+        _check(n)
+        b = np.zeros((n, 6), np.float32)
+        _check(library().rtw_scene_mesh_flat(self.h, shape, int(level), _p(b), n))
+        return b
+
+    def mesh_bins(self, width, height, bin_w, bin_h, shape=0):
+        """(offsets, entries) of the reference camera's screen bins, or None when the mesh gets none"""
+        self.commit()
+        counts = np.zeros(2, np.int64)
+        rc = library().rtw_scene_mesh_bins(self.h, shape, int(width), int(height), int(bin_w), int(bin_h), None, C.c_int64(0), None,
+                                           C.c_int64(0), _p(counts))
+        _check(rc)
+        if rc == 0:
+            return None
+        off = np.zeros(int(counts[0]), np.uint32)
+        ent = np.zeros(max(1, int(counts[1])), np.uint32)
+        _check(library().rtw_scene_mesh_bins(self.h, shape, int(width), int(height), int(bin_w), int(bin_h), _p(off), C.c_int64(len(off)),
+                                             _p(ent), C.c_int64(int(counts[1])), _p(counts)))
+        return off, ent[:int(counts[1])]
+
     def FindIntersectionWithScene(self, rays):
         """rays: (n,7) origin, direction, distance -> (hits (n,11), shape (n,), triangle (n,))"""
         self.commit()

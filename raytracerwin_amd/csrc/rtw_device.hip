@@ -1790,6 +1790,30 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                 if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
 #undef RTW_LAUNCH_TW
             }
+            if (r == 1 && tune.wave_tail && tune.wave_stage > 0) {
+                // after shade(0) / trace(0): ONE kernel finishes the frame (shade(1), trace(1), ... ) for the paths of trace list 0
+                const long long paths = items_of(1);
+                constexpr int NT = 1024;
+                RtwRenderParams pt = p;
+                long long B = (paths + (long long)tune.wave_blocks * (NT / 64) - 1) / ((long long)tune.wave_blocks * (NT / 64));
+                if (B < 1) B = 1;
+                if (B > 32) B = 32;
+                pt.wave_paths = (int)B;
+                long long blocks = (paths + B * (NT / 64) - 1) / (B * (NT / 64));
+                if (blocks < 1) blocks = 1;
+                if (blocks > tune.wave_blocks) blocks = tune.wave_blocks;
+                const size_t dyn = (size_t)(NT / 64) * RTW_WAVE_LDS_WORDS * 4 + tune.wave_stage_bytes;
+#define RTW_LAUNCH_TAIL(ST)                                                                                                              \
+                do {                                                                                                                     \
+                    if (stats) { (void)hipFuncSetAttribute((const void*)pathwave_kernel<true, ST, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                        hipLaunchKernelGGL((pathwave_kernel<true, ST, NT, true>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, pt); } \
+                    else { (void)hipFuncSetAttribute((const void*)pathwave_kernel<false, ST, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                        hipLaunchKernelGGL((pathwave_kernel<false, ST, NT, true>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, pt); } \
+                } while (0)
+                if (tune.wave_stage == 1) RTW_LAUNCH_TAIL(1); else if (tune.wave_stage == 2) RTW_LAUNCH_TAIL(2); else RTW_LAUNCH_TAIL(3);
+#undef RTW_LAUNCH_TAIL
+                break;
+            }
             long long sb = (items_of(r) + 255) / 256;
             if (sb < 1) sb = 1;
             if (sb > 262144) sb = 262144;
@@ -1808,10 +1832,10 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
             const size_t dyn = (size_t)(NT / 64) * RTW_WAVE_LDS_WORDS * 4 + tune.wave_stage_bytes;
 #define RTW_LAUNCH_PW(ST)                                                                                                                \
             do {                                                                                                                         \
-                if (stats) { (void)hipFuncSetAttribute((const void*)pathwave_kernel<true, ST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                    hipLaunchKernelGGL((pathwave_kernel<true, ST, NT>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }     \
-                else { (void)hipFuncSetAttribute((const void*)pathwave_kernel<false, ST, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                    hipLaunchKernelGGL((pathwave_kernel<false, ST, NT>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }    \
+                if (stats) { (void)hipFuncSetAttribute((const void*)pathwave_kernel<true, ST, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                    hipLaunchKernelGGL((pathwave_kernel<true, ST, NT, false>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }     \
+                else { (void)hipFuncSetAttribute((const void*)pathwave_kernel<false, ST, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                    hipLaunchKernelGGL((pathwave_kernel<false, ST, NT, false>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }    \
             } while (0)
             if (stage == 1) RTW_LAUNCH_PW(1); else if (stage == 2) RTW_LAUNCH_PW(2); else RTW_LAUNCH_PW(3);
 #undef RTW_LAUNCH_PW
@@ -1820,8 +1844,8 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
             if (blocks < 1) blocks = 1;
             if (blocks > 262144) blocks = 262144;
             const size_t dyn = 4 * RTW_WAVE_LDS_WORDS * 4;
-            if (stats) hipLaunchKernelGGL((pathwave_kernel<true, 0, 256>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
-            else hipLaunchKernelGGL((pathwave_kernel<false, 0, 256>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
+            if (stats) hipLaunchKernelGGL((pathwave_kernel<true, 0, 256, false>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
+            else hipLaunchKernelGGL((pathwave_kernel<false, 0, 256, false>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
         }
     } else if (p.wavefront) {
         // shade(0), then trace(r) / shade(r + 1): a path queued with a hit record ends at the latest in shade(max_bounce - 1),

@@ -482,12 +482,15 @@ __global__ __launch_bounds__(NT) void trace_wave_kernel(const RtwSceneDev* __res
     if (STATS) flush_counters(sc, ct);
 }
 
-template <bool STATS, int STAGE, int NT>
+// RESUME: the paths are those of the first trace round's list (their state and the hit record of their second segment
+// are in the dense slot arrays): the kernel finishes what is left of the frame after the one big trace round, where the
+// later rounds' handful of rays would each pay a launch.
+template <bool STATS, int STAGE, int NT, bool RESUME>
 __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathwave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
     const uint32_t B = (uint32_t)p.wave_paths;
-    const uint32_t nq = pb.counters[0];
+    const uint32_t nq = RESUME ? pb.counters[4] : pb.counters[0];
     const uint32_t n = nq < pb.capacity ? nq : pb.capacity;
     if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) * B >= n) return;     // (whole block) the grid is sized from the previous pass's queue length
     uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
@@ -501,15 +504,17 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
     for (uint32_t base = wave * B; base < n; base += nwaves * B) {
-        const uint32_t q = base + (uint32_t)lane;
-        bool alive = (uint32_t)lane < B && q < n;
+        const uint32_t kq = base + (uint32_t)lane;
+        bool alive = (uint32_t)lane < B && kq < n;
+        const uint32_t q = RESUME ? (alive ? pb.tlist0[kq] : 0u) : kq;
+        if (RESUME && q >= pb.capacity) alive = false;
         uint32_t pid = 0;
         PathRng rng; rng.key = 0; rng.counter = 0; rng.table_base = 0; rng.table_reads = 0;
         Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.dist = 0.0f;
         int depth = 0, nlev = 0;
         bool have_hit = false;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        if (alive) {
+        if (alive && !RESUME) {
             const uint32_t qe = pb.queue[q];
             pid = qe & 0x7FFFFFFFu;
             const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
@@ -519,6 +524,18 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
             depth = p.max_bounce;
             have_hit = !(qe >> 31);                      // else: an untame camera ray, its first segment is traced like any other
             if (have_hit) { r0 = pb.hitrec[(size_t)pid * 2]; r1 = pb.hitrec[(size_t)pid * 2 + 1]; }     // the primary kernel files hit records under the path id
+        }
+        if (alive && RESUME) {                           // as shade_kernel picks a path up in round 1
+            pid = pb.queue[q] & 0x7FFFFFFFu;
+            const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
+            const int pixel = work_to_pixel(p, wi);
+            const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1], s2 = pb.state[(size_t)q * 3 + 2];
+            ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+            rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
+            rng.table_base = (((uint64_t)pass_of(p) * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
+            nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
+            have_hit = true;
+            r0 = pb.hitslot[(size_t)q * 2]; r1 = pb.hitslot[(size_t)q * 2 + 1];
         }
         LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
         for (;;) {

@@ -94,6 +94,7 @@ struct rtw_context {
     int use_graph = 1;                  // rtw_render_passes: replay a captured pass (0 = launch every pass kernel by kernel)
     int debug_primary = 0;              // timing experiments only (wrong images): 1 no gamma, 2 no accumulator traffic, 4 no bins loop
     int primary_blocks_per_cu = 64;     // pipeline 3: persistent primary kernel, blocks of 256 threads per CU
+    int wave_tail = 0;                  // pipeline 3: 1 = after the first trace round one kernel finishes the frame (measured slower: register-bound)
     int wave_fused = 0;                 // pipeline 3: 1 = one kernel carries the paths to their end, 0 = a launch per bounce
     int wave_paths = 0;                 // pipeline 3: paths per wave of the path kernel (0 = chosen from the queue length)
     int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
@@ -237,6 +238,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         ctx->primary_blocks_per_cu = value;
         return RTW_OK;
     }
+    if (std::strcmp(name, "wave_tail") == 0) { ctx->wave_tail = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "wave_fused") == 0) {
         if (value != 0 && value != 1) return fail(RTW_ERR_INVALID, "wave_fused must be 0 or 1");
         ctx->wave_fused = value;
@@ -540,6 +542,33 @@ int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int
     return (int)m.quads.size();
 }
 
+int rtw_scene_mesh_flat(const rtw_scene* scene, int shape, int level, float* boxes6, int max_entries)
+{
+    if (!scene || shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
+    if (level < 0 || level > 2) return fail(RTW_ERR_INVALID, "level must be 0, 1 or 2");
+    const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
+    const int n = m.flat_n[level] < max_entries ? m.flat_n[level] : max_entries;
+    if (boxes6) for (int i = 0; i < n; i++) for (int c = 0; c < 6; c++)
+        boxes6[(size_t)i * 6 + c] = m.flat[level][(size_t)c * (size_t)m.flat_pad[level] + (size_t)i];
+    return m.flat_n[level];
+}
+
+int rtw_scene_mesh_bins(const rtw_scene* scene, int shape, int width, int height, int bin_w, int bin_h,
+                        uint32_t* offsets, int64_t max_offsets, uint32_t* entries, int64_t max_entries, int64_t* counts2)
+{
+    if (!scene || shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
+    if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
+    if (!counts2) return fail(RTW_ERR_INVALID, "null argument");
+    std::vector<uint32_t> off, ent;
+    const bool ok = rtw::build_bins(*scene->meshes[(size_t)shape], width, height, bin_w, bin_h, off, ent);
+    counts2[0] = ok ? (int64_t)off.size() : 0; counts2[1] = ok ? (int64_t)off.back() : 0;
+    if (!ok) return 0;                   // this mesh gets no bins (not wholly in front of the camera, or the frame does not tile)
+    if (offsets) std::memcpy(offsets, off.data(), (size_t)std::min<int64_t>(max_offsets, (int64_t)off.size()) * 4);
+    if (entries) std::memcpy(entries, ent.data(), (size_t)std::min<int64_t>(max_entries, (int64_t)off.back()) * 4);
+    return 1;
+}
+
 // ---- ray-level queries ------------------------------------------------------------------------------------
 namespace {
 struct DevBuf {
@@ -816,7 +845,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
         p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
         p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
-        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
+        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
             const rtw::HostMesh& m0 = *scene->meshes[0];

@@ -306,11 +306,12 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     # (pipeline, packets, path_lanes, wave_fused, wave_stage): 3 = screen bins + a wave per secondary ray
     for mode, packets, lanes, fused, stage in ((0, 0, 4, 0, -1), (1, 0, 4, 0, -1), (1, 0, 1, 0, -1), (1, 1, 4, 0, -1), (1, 1, 1, 0, -1), (1, 0, 16, 0, -1),
                                                (1, 1, 16, 0, -1), (2, 1, 16, 0, -1), (3, 1, 16, 0, -1), (3, 1, 16, 1, -1), (3, 1, 16, 0, 0),
-                                               (3, 1, 16, 0, 1), (3, 1, 16, 1, 2)):
+                                               (3, 1, 16, 0, 1), (3, 1, 16, 1, 2), (3, 1, 16, 2, -1), (3, 1, 16, 2, 2)):
         ctx.set_option("pipeline", mode)
         ctx.set_option("packets", packets)
         ctx.set_option("path_lanes", lanes)
-        ctx.set_option("wave_fused", fused)
+        ctx.set_option("wave_fused", 1 if fused == 1 else 0)         # fused: 1 = one kernel for all bounces, 2 = one kernel after the first trace round
+        ctx.set_option("wave_tail", 1 if fused == 2 else 0)
         ctx.set_option("wave_stage", stage)
         ctx.stats_enable(True)
         ctx.stats_reset()
@@ -321,6 +322,7 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     ctx.set_option("packets", 1)
     ctx.set_option("path_lanes", 16)
     ctx.set_option("wave_fused", 0)
+    ctx.set_option("wave_tail", 0)
     ctx.set_option("wave_stage", -1)
     keys = ("rays", "shaded_hits", "tex_samples", "camera_rays")     # box / triangle test counts depend on the walk
     for o in out[1:]:
@@ -344,3 +346,26 @@ def test_quad_walk_equals_binary_walk(ctx, mesh, ns, depth):
             ref = (a, b)
         else:
             assert (bits(a) == bits(ref[0])).all() and (b == ref[1]).all(), (trav, prune)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,ns,depth,world", [("TorusKnot", 1, 4, 1), ("BlenderMonkey", 4, 3, 1), ("TorusKnot", 2, 4, 2)])
+def test_render_passes_graph_replay_equals_pass_by_pass(ctx, mesh, ns, depth, world):
+    """rtw_render_passes (UpdateBitmapPixels' sample loop: a captured launch graph replayed with the pass index on the
+    device) accumulates exactly what pass-by-pass rtw_render_tasks calls do, from any first pass, with the graph on or off."""
+    W, H = 640, 360
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.8, 0.9, 1.0)))
+    ref = R.Framebuffer(ctx, W, H)
+    for rank in range(world):
+        for p in range(3, 3 + 9):
+            s.render_tasks(ref, 10, rank, world, depth, None, p, ns, 77)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    for graph in (1, 0):
+        ctx.set_option("use_graph", graph)
+        fb = R.Framebuffer(ctx, W, H)
+        for rank in range(world):
+            s.render_passes(fb, 10, rank, world, depth, None, 3, 5, ns, 77)     # first call: plain passes, then the graph
+            s.render_passes(fb, 10, rank, world, depth, None, 8, 4, ns, 77)     # second call: continues the sequence
+        a, b = fb.read_float(), fb.resolve_argb()
+        assert (bits(a) == bits(ra)).all() and (b == rb).all(), graph
+    ctx.set_option("use_graph", 1)

@@ -169,3 +169,81 @@ def test_quad_tree_is_an_order_preserving_collapse_of_the_reference_tree(name):
     leaf = g["tree_tri"] >= 0
     assert order == g["tree_tri"][leaf].tolist()
     assert (bits(np.array(boxes)) == bits(g["tree_bounds"][leaf])).all()
+
+
+@pytest.mark.parametrize("name", ["TorusKnot", "BlenderMonkey", "unitychan"])
+def test_flat_hierarchy_is_the_reference_leaves_in_preorder_under_unions(name):
+    """Level 0 of the flat hierarchy = the reference tree's leaf boxes in preorder, bit for bit (the walk gives each
+    leaf's OWN box the reference's test); every entry of level 1 / 2 is the exact union of its 16 children."""
+    g = np.load(os.path.join(GOLDEN, "mesh_%s.npz" % name))
+    s = R.RayTracerScene(None)
+    s.AddShape(R.RMeshShape.Create(asset(name + ".obj")))
+    leaf = g["tree_tri"] >= 0
+    l0, l1, l2 = s.mesh_flat(0), s.mesh_flat(1), s.mesh_flat(2)
+    assert (bits(l0) == bits(g["tree_bounds"].reshape(-1, 6)[leaf])).all()
+    for child, parent in ((l0, l1), (l1, l2)):
+        assert len(parent) == (len(child) + 15) // 16
+        for k in range(len(parent)):
+            c = child[16 * k:16 * k + 16]
+            assert (parent[k, :3] == c[:, :3].min(axis=0)).all() and (parent[k, 3:] == c[:, 3:].max(axis=0)).all()     # values (+0 == -0)
+
+
+def _camera_dirs(W, H, xs, ys, ox, oy):
+    """ThreadWorker_Render's ray direction (Src/RayTracerProgram.cpp:141-165) in float32, before normalisation
+    (normalising scales all three components alike and cannot change which boxes the line meets)."""
+    f = np.float32
+    aspect = f(W) / f(H)
+    dx = -(xs - W // 2).astype(f) / f(W * 2) * aspect
+    dy = -(ys - H // 2).astype(f) / f(H * 2)
+    d = np.stack([dx + ox.astype(f), dy + oy.astype(f), np.full(len(xs), -0.5, f)], 1)
+    return d / np.sqrt((d.astype(np.float64) ** 2).sum(1)).astype(f)[:, None]
+
+
+@pytest.mark.parametrize("name,W,H,bw,bh,step", [("TorusKnot", 192, 108, 16, 4, 3), ("TorusKnot", 96, 54, 32, 2, 1), ("TorusKnot", 128, 72, 64, 1, 2),
+                                                 ("BlenderMonkey", 192, 108, 16, 4, 3), ("unitychan", 192, 108, 16, 4, 29)])
+def test_screen_bins_hold_every_leaf_a_camera_ray_can_meet(name, W, H, bw, bh, step):
+    """The bins only have to be a superset: for camera rays of every (sampled) pixel -- jitter corners, centre and random
+    offsets inside the sub-sample range -- every leaf whose box passes the reference's line test must be in the pixel's bin,
+    and every bin lists its leaves in ascending (= preorder) order."""
+    s = R.RayTracerScene(None)
+    s.AddShape(R.RMeshShape.Create(asset(name + ".obj")))
+    off, ent = s.mesh_bins(W, H, bw, bh)
+    bounds, _, tri = s.mesh_nodes()
+    assert len(off) == (W // bw) * (H // bh) + 1
+    for b in range(len(off) - 1):
+        e = ent[off[b]:off[b + 1]]
+        assert (np.diff(e.astype(np.int64)) > 0).all() and (tri[e] >= 0).all()
+    leaf_nodes = np.nonzero(tri >= 0)[0]
+    lo, hi = bounds[leaf_nodes, :3], bounds[leaf_nodes, 3:]
+    nn = np.int64(len(bounds))
+    keys = np.repeat(np.arange(len(off) - 1, dtype=np.int64), np.diff(off.astype(np.int64))) * nn + ent.astype(np.int64)     # (bin, leaf) pairs
+    rng = np.random.default_rng(7)
+    r = np.float32(1.0) / np.float32(W * 4)
+    pix = np.arange(0, W * H, step)
+    xs, ys = pix % W, pix // W
+    bins = ((ys // bh) * (W // bw) + xs // bw).astype(np.int64)
+    offsets = [(-0.25, -0.25), (1.25, -0.25), (-0.25, 1.25), (1.25, 1.25), (0.5, 0.5)] + [tuple(rng.uniform(-0.25, 1.25, 2)) for _ in range(3)]
+    o = np.array([0, 0, 7], np.float32)
+    missing = 0
+    for fx, fy in offsets:
+        d = _camera_dirs(W, H, xs, ys, np.full(len(xs), fx * r), np.full(len(xs), fy * r))
+        inv = np.float32(1.0) / d
+        for c0 in range(0, len(xs), 2048):
+            sl = slice(c0, c0 + 2048)
+            t1 = (lo[None] - o) * inv[sl, None, :]
+            t2 = (hi[None] - o) * inv[sl, None, :]
+            hit = np.maximum(t1, t2).min(2) > np.minimum(t1, t2).max(2)       # RRay::TestIntersectionWithAabb, strict
+            pi, li = np.nonzero(hit)
+            missing += int((~np.isin(bins[c0 + pi] * nn + leaf_nodes[li], keys)).sum())
+    assert missing == 0
+
+
+def test_meshes_reaching_behind_the_camera_get_no_bins(tmp_path):
+    """A leaf box that is not wholly in front of the camera (z >= 7) cannot be binned: the mesh then has no bins and the
+    primary kernel walks its tree instead."""
+    p = tmp_path / "near.obj"
+    p.write_text("v 0 0 6\nv 1 0 8\nv 0 1 6\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n")
+    s = R.RayTracerScene(None)
+    s.AddShape(R.RMeshShape.Create(str(p)))
+    assert s.mesh_bins(192, 108, 16, 4) is None
+    assert s.mesh_bins(100, 108, 16, 4) is None        # a frame the bins do not tile
