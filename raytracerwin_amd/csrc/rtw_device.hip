@@ -1780,7 +1780,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                 do {                                                                                                                            \
                     long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);                                                                      \
                     if (blocks < 1) blocks = 1;                                                                                                 \
-                    if (blocks > (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? 8 : 1)) blocks = (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? 8 : 1); \
+                    if (blocks > (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? tune.wave_blocks_mul : 1)) blocks = (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? tune.wave_blocks_mul : 1); \
                     const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4 + (ST == 0 ? 0 : tune.wave_stage_bytes);                     \
                     if (stats) { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<true, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
                         hipLaunchKernelGGL((trace_wave_kernel<true, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \

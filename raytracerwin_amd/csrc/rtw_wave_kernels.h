@@ -21,6 +21,9 @@
 // pipelines execute (same helpers).
 
 #define RTW_WAVE_LDS_WORDS 256      // per wave: 64 level-2 hits, 64 level-1 hits, 128 candidate leaves
+#ifndef RTW_TRACEWAVE_MINW
+#define RTW_TRACEWAVE_MINW 1     // (8 = 64 VGPRs with a small spill measured slower than the natural 75 VGPRs / 6 waves per SIMD)
+#endif
 #ifndef RTW_PATHWAVE_MINW
 #define RTW_PATHWAVE_MINW 4
 #endif
@@ -455,7 +458,7 @@ __device__ __forceinline__ FlatSrc stage_shape0(const RtwSceneDev* __restrict__ 
 // The wavefront pipeline's trace step (see trace_kernel) with the whole wave on one ray: the ray comes in through scalar
 // loads, the walk is wave_walk_flat on the arrays the block staged in LDS.  Persistent blocks, one per CU when staged.
 template <bool STATS, int STAGE, int NT>
-__global__ __launch_bounds__(NT) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
+__global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
     const uint32_t n = pb.counters[4 + round];

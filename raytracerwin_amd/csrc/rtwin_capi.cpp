@@ -76,7 +76,9 @@ struct rtw_context {
     int known_paths = -1;               // queue length of the latest pass whose copy has completed
     int known_rounds[32];               // wavefront: trace-list lengths of that pass
     int cu_count = 256;
-    int wave_stage = -1;                // pipeline 3: LDS staging of shape 0 in the path kernel (-1 = as much as fits, 0..3 = fixed)
+    int wave_stage = 0;                 // pipeline 3: LDS staging of shape 0 in the trace kernels: 0 = none (measured fastest: more waves in flight
+                                        // beat LDS residency), 1..3 = levels / leaves / triangles, -1 = as much as fits
+    int wave_blocks_mul = 8;
     // a whole pass captured as a launch graph and replayed with the pass index on the device (rtw_render_passes)
     struct PassGraph {
         bool valid = false;
@@ -225,6 +227,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         ctx->pipeline = value;
         return RTW_OK;
     }
+    if (std::strcmp(name, "wave_blocks_mul") == 0) { ctx->wave_blocks_mul = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_stage") == 0) {
         if (value < -1 || value > 3) return fail(RTW_ERR_INVALID, "wave_stage must be -1 (automatic) or 0..3");
         ctx->wave_stage = value;
@@ -845,7 +848,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
         p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
         p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
-        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
+        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
             const rtw::HostMesh& m0 = *scene->meshes[0];
