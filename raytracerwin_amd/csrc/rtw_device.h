@@ -32,6 +32,7 @@ struct PipelineTuning {
     int round_hint[32];    // wavefront: trace-list lengths of the previous pass per round, -1 = unknown
     int wave_stage;        // bins + wave pipeline: what pathwave_kernel's blocks stage in LDS for shape 0 (0 nothing .. 3 levels + triangles)
     size_t wave_stage_bytes;   // bytes of those arrays
+    bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
     int wave_blocks_mul;   // unstaged trace rounds: at most wave_blocks * 4 * wave_blocks_mul blocks of 4 waves (a wave takes rays in turn)
     int wave_tail;         // 1: after the first trace round one kernel finishes the frame (no launch per later bounce)
     int wave_fused;        // 1: pathwave_kernel carries the paths to their end, 0: one shade + one wave-per-ray trace launch per bounce

@@ -1624,6 +1624,20 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restr
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
     }
     if (p.pass_ptr && blockIdx.x == 0 && threadIdx.x == 0) *p.pass_ptr += 1;       // last kernel of the pass; nothing here reads the pass index
+    if (p.self_clean) {
+        // Last kernel of the pass: the last block to finish files the counters for the host (queue lengths, sizes of the next
+        // launches) and zeroes them for the next pass, which saves that pass a memset launch.  Every block has read the one
+        // counter it needs (n, above) before it takes its ticket.
+        __shared__ uint32_t last_block;
+        __syncthreads();
+        if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (last_block && threadIdx.x < 64) {
+            const uint32_t v = threadIdx.x == 40 ? 0u : pb.counters[threadIdx.x];
+            pb.counters[64 + threadIdx.x] = v;
+            pb.counters[threadIdx.x] = 0u;
+        }
+    }
 }
 
 template <bool STATS>
@@ -1701,7 +1715,7 @@ size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLa
     l.queue_off = 0;
     l.pend_off = l.queue_off + up(n * 4 * 4);
     l.counters_off = l.pend_off + up(n * 4);
-    l.rad_off = l.counters_off + 256;
+    l.rad_off = l.counters_off + 1024;      // 64 counters | 64 words: their values at the end of the previous pass (read back by the host) | spare
     l.hit_off = l.rad_off + up(n * 4 * 16);
     l.ws_off = l.hit_off + up(n * 4 * 32);
     l.total = l.ws_off + ((size_t)l.path_quartets + 256) * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
@@ -1732,7 +1746,8 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     PipeBufs pb;
     pb.queue = (uint32_t*)(w + l.queue_off); pb.pend = (uint32_t*)(w + l.pend_off); pb.counters = (uint32_t*)(w + l.counters_off);
     pb.rad = (float4*)(w + l.rad_off); pb.hitrec = (float4*)(w + l.hit_off); pb.ws = (float4*)(w + l.ws_off);
-    hipError_t e = hipMemsetAsync(pb.counters, 0, 256, stream);
+    hipError_t e = hipSuccess;
+    if (!tune.counters_clean) e = hipMemsetAsync(pb.counters, 0, 256, stream);     // else: the previous pass's resolve_kernel left them zeroed
     if (e != hipSuccess) return (int)e;
     if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "memset -> %s (wavefront %d packets %d)\n", hipGetErrorString(hipPeekAtLastError()), p.wavefront, p.packets);
     pb.hitslot = pb.hitrec; pb.state = nullptr; pb.tlist0 = pb.tlist1 = nullptr; pb.capacity = 0;
@@ -1751,6 +1766,10 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     const int block = 256;
     const int grid = (p.count + block - 1) / block;
     int resolve_blocks = grid < 1024 ? grid : 1024;
+    if (p.wavefront == 2 && tune.expected_paths >= 0) {      // a thread per pending pixel (at most one per queued path), not per pixel of the frame
+        const int want = (tune.expected_paths + tune.expected_paths / 4 + 1024 + 255) / 256;
+        if (want < resolve_blocks) resolve_blocks = want;
+    }
     if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
     if (p.wavefront == 2) {
         const int pgrid = grid < tune.wave_blocks * tune.primary_blocks_per_cu ? grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // persistent waves

@@ -120,6 +120,8 @@ struct RtwRenderParams {
     int32_t row0, nrows;            // contiguous range: first screen row and number of rows; task partition: number of virtual rows
     int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
     int32_t pad_params;
+    int32_t self_clean;             // resolve_kernel files the counters at word 64.. and zeroes them for the next pass
+    int32_t pad_params2;
     const struct RtwBinsDev* bins;  // [n_shapes] or null
     int32_t* pass_ptr;              // not null: the pass index lives on the device (replayed launch graphs); resolve_kernel adds 1 to it
     const uint32_t* tile_order;     // full-frame launches: the order in which the primary kernel takes the tiles (null = as numbered)

@@ -79,6 +79,8 @@ struct rtw_context {
     int wave_stage = 0;                 // pipeline 3: LDS staging of shape 0 in the trace kernels: 0 = none (measured fastest: more waves in flight
                                         // beat LDS residency), 1..3 = levels / leaves / triangles, -1 = as much as fits
     int wave_blocks_mul = 8;
+    const void* clean_ws = nullptr;     // workspace and counters offset whose counters the last pass left zeroed (bins + wave pipeline)
+    size_t clean_off = 0;
     // a whole pass captured as a launch graph and replayed with the pass index on the device (rtw_render_passes)
     struct PassGraph {
         bool valid = false;
@@ -145,6 +147,7 @@ int ensure_workspace(rtw_context* ctx, size_t bytes)
     if (bytes <= ctx->workspace_bytes) return RTW_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->d_workspace) { (void)hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_bytes = 0; }
+    ctx->clean_ws = nullptr;
     HIP_TRY(hipMalloc(&ctx->d_workspace, bytes));
     ctx->workspace_bytes = bytes;
     return RTW_OK;
@@ -622,6 +625,7 @@ int rtw_ray_trace(rtw_scene* scene, const float* rays, const uint32_t* keys2, in
     HIP_TRY(hipMemcpyAsync(dr.p, rays, (size_t)n * 28, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dk.p, keys2, (size_t)n * 8, hipMemcpyHostToDevice, st));
     rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(n, max_bounce)); if (rc != RTW_OK) return rc;
+    scene->ctx->clean_ws = nullptr;      // the level store below overwrites the pipelines' counters
     hipError_t e = (hipError_t)rtw::launch_ray_trace(scene->d_scene, (const float*)dr.p, (const uint32_t*)dk.p, n, max_bounce, use_base_color, seed,
                                                      (unsigned long long)width * (unsigned long long)height, (float*)dc.p, scene->ctx->d_workspace,
                                                      scene->ctx->stats_enabled, st);
@@ -875,9 +879,14 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         }
         tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
         tune.path_variant = cx->path_variant;
+        const size_t coff = rtw::pipeline_counters_offset(p.count, max_bounce);
+        p.self_clean = p.wavefront == 2 ? 1 : 0;
+        tune.counters_clean = p.self_clean && cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
+        cx->clean_ws = nullptr;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
+        if (e == hipSuccess && p.self_clean) { cx->clean_ws = cx->d_workspace; cx->clean_off = coff; }
         if (e == hipSuccess && !cx->counters_pending && !capturing && (cx->known_shape != shape || (cx->hint_tick++ % cx->hint_period) == 0)) {     // one copy in flight at a time; its value is used once it has landed
-            const size_t off = rtw::pipeline_counters_offset(p.count, max_bounce);
+            const size_t off = coff + (p.self_clean ? 256 : 0);       // a self-cleaning pass files its counters 64 words further
             if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + off, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
                 hipEventRecord(cx->counters_event, cx->stream) == hipSuccess) {
                 cx->counters_pending = true; cx->counters_shape = shape;
@@ -885,6 +894,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         }
     } else {
         int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
+        scene->ctx->clean_ws = nullptr;
         e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
     }
     if (e != hipSuccess) return hip_fail(e, "render_kernel launch");
@@ -940,7 +950,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
         const int pass = first_pass + i;
         const bool same = g.valid && g.scene == scene && g.fb == fb && g.task_rows == task_rows && g.rank == rank && g.world == world &&
                           g.max_bounce == max_bounce && g.preview == (use_base_color ? 1 : 0) && g.sub_samples == sub_samples && g.seed == seed;
-        if (same && cx->use_graph && !cx->stats_enabled && !cx->kernel_timing) {
+        if (same && cx->use_graph && !cx->stats_enabled && !cx->kernel_timing && cx->clean_ws != nullptr && cx->clean_ws == cx->d_workspace) {
             if (g.next_pass != pass) {           // a new sequence: set the device's pass index
                 *cx->h_pass = pass;
                 HIP_TRY(hipMemcpyAsync(cx->d_pass, cx->h_pass, sizeof(int32_t), hipMemcpyHostToDevice, cx->stream));
