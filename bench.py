@@ -277,7 +277,10 @@ def main():
         run_bytes = algorithmic_bytes(st_run, npix) / world
         # the three launches of one rtw_render_* call are priced together ("render pass"); at N=1 their event
         # durations are summed, for N>1 the whole-loop event time per step is used
-        pass_ms = sum(kernel_parts) if (kernel_parts and world == 1) else kernel_ms
+        # "launch duration" of a render pass = HIP events on the launch stream around the K timed steps, divided by K
+        # (the pass is several dependent launches; the per-stage event durations below are reported beside it -- recording
+        # events between the stages perturbs them, so their sum is not used)
+        pass_ms = kernel_ms
         achieved = alg_bytes / (pass_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
@@ -302,7 +305,7 @@ def main():
                          "kernel": ("render pass = primary_bins_kernel + per-bounce shade_kernel / trace_wave_kernel rounds + resolve_kernel (one rtw_render_tasks call)" if args.pipeline == 3
                                     else "render pass = primary_kernel + path kernels + resolve_kernel (one rtw_render_tasks call)" if args.pipeline >= 1 else "render_kernel"),
                          "kernel_ms": pass_ms,
-                         "kernels_ms": dict(zip(("primary", "bounce_rounds", "resolve"), kernel_parts)) if kernel_parts else None,
+                         "stage_ms_with_events_between": dict(zip(("primary", "bounce_rounds", "resolve"), kernel_parts)) if kernel_parts else None,
                          "loop_ms_per_step_hip_events": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "executed_bytes_per_launch": run_bytes,
