@@ -74,6 +74,9 @@ struct PathRng {
     uint32_t key, counter;
     uint64_t table_base;    // first unit-table index of the path, phase included, before the modulo
     uint32_t table_reads;
+    // the unit-table entry the NEXT hemisphere draw will read, fetched ahead of the shading chain (valid while
+    // pre_reads == table_reads); a latency optimisation only: the value is the one the draw would load
+    uint32_t pre_reads; float pre_x, pre_y, pre_z;
     __device__ __forceinline__ float random()            // RMath::Random (Src/Math.h:17-20)
     {
         uint32_t r = mix32(key + counter++) >> 1;
@@ -87,6 +90,7 @@ __device__ __forceinline__ void rng_init(PathRng& r, uint32_t seed, uint32_t pha
     r.counter = 0;
     r.table_base = (((uint64_t)pass * npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
     r.table_reads = 0;
+    r.pre_reads = 0xFFFFFFFFu; r.pre_x = r.pre_y = r.pre_z = 0.0f;
 }
 
 struct Counters { uint32_t rays, boxes, tris, hits, tex, cams; };
@@ -849,14 +853,24 @@ __device__ __forceinline__ uint32_t mod_table_size(uint64_t x)
     if (s >= RTW_TABLE_SIZE) s -= RTW_TABLE_SIZE;
     return s;
 }
+// issue the loads of the unit-table entry the next hemisphere draw of this path will use
+__device__ __forceinline__ void prefetch_unit_vector(const RtwSceneDev* __restrict__ sc, PathRng& rng)
+{
+    uint32_t idx = mod_table_size(rng.table_base + rng.table_reads);
+    if (sc->debug_table_mask) idx &= (uint32_t)sc->debug_table_mask;
+    const float* e = sc->unit_table;
+    rng.pre_x = gld1(e, (size_t)idx * 3); rng.pre_y = gld1(e, (size_t)idx * 3 + 1); rng.pre_z = gld1(e, (size_t)idx * 3 + 2);
+    rng.pre_reads = rng.table_reads;
+}
 __device__ __forceinline__ f3 hemisphere_direction(const RtwSceneDev* __restrict__ sc, f3 normal, PathRng& rng)
 {
     uint32_t idx = mod_table_size(rng.table_base + rng.table_reads);   // RMath::PseudoRandomUnitVector, per-path cursor
     if (sc->debug_table_mask) idx &= (uint32_t)sc->debug_table_mask;
+    const bool fetched = rng.pre_reads == rng.table_reads;
     rng.table_reads++;
     if (!RTW_IN_RANGE(sc, 4, idx, RTW_TABLE_SIZE)) return normal;
     const float* e = sc->unit_table;
-    const f3 v = mk(gld1(e, (size_t)idx * 3), gld1(e, (size_t)idx * 3 + 1), gld1(e, (size_t)idx * 3 + 2));
+    const f3 v = fetched ? mk(rng.pre_x, rng.pre_y, rng.pre_z) : mk(gld1(e, (size_t)idx * 3), gld1(e, (size_t)idx * 3 + 1), gld1(e, (size_t)idx * 3 + 2));
     if (dot(v, normal) > 0.0f) return v;                                          // Src/Math.cpp:42-54
     return reflect(v, normal);
 }
@@ -1483,7 +1497,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
                 rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
                 rng.table_base = (((uint64_t)pass_of(p) * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
                 nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
+                rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
             }
+            if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
             LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
             f3 L = mk(0, 0, 0);
             bool done = false;

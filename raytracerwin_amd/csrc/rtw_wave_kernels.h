@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
         const uint32_t q = RESUME ? (alive ? pb.tlist0[kq] : 0u) : kq;
         if (RESUME && q >= pb.capacity) alive = false;
         uint32_t pid = 0;
-        PathRng rng; rng.key = 0; rng.counter = 0; rng.table_base = 0; rng.table_reads = 0;
+        PathRng rng; rng.key = 0; rng.counter = 0; rng.table_base = 0; rng.table_reads = 0; rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
         Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.dist = 0.0f;
         int depth = 0, nlev = 0;
         bool have_hit = false;

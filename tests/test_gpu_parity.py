@@ -369,3 +369,22 @@ def test_render_passes_graph_replay_equals_pass_by_pass(ctx, mesh, ns, depth, wo
         a, b = fb.read_float(), fb.resolve_argb()
         assert (bits(a) == bits(ra)).all() and (b == rb).all(), graph
     ctx.set_option("use_graph", 1)
+
+
+@pytest.mark.gpu
+def test_config5_shape_4k_depth8_pipelines_agree_and_tasks_compose(ctx):
+    """BASELINE configs[4] at its full frame size (unitychan + textures, 3840x2160, depth 8; one 4-spp pass of the 16 spp):
+    the default bins + wave pipeline gives the bits of the packet / path-kernel pipeline, and the frame dealt as 10-row tasks
+    over 8 ranks (rendered one after another into one buffer) equals the one-rank frame."""
+    W, H = 3840, 2160
+    s = gpu_scene(ctx, "unitychan", R.SurfaceMaterial_Diffuse((1, 1, 1)))
+    ctx.set_option("pipeline", 1)
+    a1, b1 = render_frame(ctx, s, W, H, 4, 8, 0, 2024, 3, 1)
+    ctx.set_option("pipeline", 3)
+    a3, b3 = render_frame(ctx, s, W, H, 4, 8, 0, 2024, 3, 1)
+    assert (bits(a1) == bits(a3)).all() and (b1 == b3).all()
+    fb = R.Framebuffer(ctx, W, H)
+    for rank in range(8):
+        s.render_tasks(fb, 10, rank, 8, 8, None, 3, 4, 2024)
+    a8, b8 = fb.read_float(), fb.resolve_argb()
+    assert (bits(a8) == bits(a3)).all() and (b8 == b3).all()
