@@ -1788,7 +1788,8 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
     if (p.wavefront == 2) {
-        const int pgrid = grid < tune.wave_blocks * tune.primary_blocks_per_cu ? grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // persistent waves
+        const int jobs_grid = p.tile_order ? (p.n_jobs + 3) / 4 : grid;        // a wave per job (a tile, or a tile's sub-sample)
+        const int pgrid = jobs_grid < tune.wave_blocks * tune.primary_blocks_per_cu ? jobs_grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // else waves take jobs in turn
         if (stats) hipLaunchKernelGGL(primary_bins_kernel<true>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL(primary_bins_kernel<false>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     } else if (p.packets) {

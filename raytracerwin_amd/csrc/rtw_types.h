@@ -78,8 +78,9 @@ struct RtwShapeDev {
     const RtwWide* wides;           // BFS order; null / n_wides == 0 -> no 16-lane walk
     int32_t n_wides, wide_depth;
     // flat hierarchy over the leaves in preorder (16 consecutive entries of a level share one entry of the next):
-    // level 0 = the leaves' own boxes, 1 = groups of 16 leaves, 2 = groups of 256.  Each level is six float arrays
-    // (min x/y/z, max x/y/z) of flat_pad[l] entries, component c of entry i at flat[l][c * flat_pad[l] + i].
+    // level 0 = the leaves' own boxes, 1 = groups of 16 leaves, 2 = groups of 256.  Entry i of a level is the 24 bytes
+    // flat[l][6 i ..]: (min x, max x), (min y, max y), (min z, max z) -- one pair per axis, so that (pair - origin) * reciprocal
+    // is one packed subtract and one packed multiply; flat_pad[l] entries are allocated (whole waves may read past flat_n[l]).
     const float* flat[3];
     int32_t flat_n[3], flat_pad[3];
     int32_t pad_flat0, pad_flat1;
@@ -121,7 +122,7 @@ struct RtwRenderParams {
     int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
     int32_t pad_params;
     int32_t self_clean;             // resolve_kernel files the counters at word 64.. and zeroes them for the next pass
-    int32_t pad_params2;
+    int32_t n_jobs;                 // entries of tile_order
     const struct RtwBinsDev* bins;  // [n_shapes] or null
     int32_t* pass_ptr;              // not null: the pass index lives on the device (replayed launch graphs); resolve_kernel adds 1 to it
     const uint32_t* tile_order;     // full-frame launches: the order in which the primary kernel takes the tiles (null = as numbered)

@@ -49,20 +49,22 @@ struct FlatRay { f3 o; float ix, iy, iz, eps_t; bool skx, sky, skz; };   // sk*:
 // level, plus the conservative segment clip when `prune`
 // LDSB: the level's arrays were staged in LDS by the block (same layout).  EXACT: the ray is not "tame" (a direction
 // component below FLT_EPSILON, NaN, ...): the reference's test as written (skipped axes, Math::Min/Max), no clip.
+typedef float rtw_v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const rtw_v2f rtw_g_v2;
+typedef __attribute__((address_space(3))) const rtw_v2f rtw_l_v2;
 template <bool LDSB, bool EXACT>
 __device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pad, int idx, const FlatRay& fr, bool prune, float far_t)
 {
-    float mnx, mny, mnz, mxx, mxy, mxz;
-    if (LDSB) {
-        mnx = lld1(b, idx); mny = lld1(b, pad + idx); mnz = lld1(b, 2 * pad + idx);
-        mxx = lld1(b, 3 * pad + idx); mxy = lld1(b, 4 * pad + idx); mxz = lld1(b, 5 * pad + idx);
-    } else {
-        mnx = gld1(b, (size_t)idx); mny = gld1(b, (size_t)pad + idx); mnz = gld1(b, (size_t)2 * pad + idx);
-        mxx = gld1(b, (size_t)3 * pad + idx); mxy = gld1(b, (size_t)4 * pad + idx); mxz = gld1(b, (size_t)5 * pad + idx);
-    }
-    const float x1 = (mnx - fr.o.x) * fr.ix, x2 = (mxx - fr.o.x) * fr.ix;
-    const float y1 = (mny - fr.o.y) * fr.iy, y2 = (mxy - fr.o.y) * fr.iy;
-    const float z1 = (mnz - fr.o.z) * fr.iz, z2 = (mxz - fr.o.z) * fr.iz;
+    (void)pad;
+    // the entry's three (min, max) pairs; (pair - origin) * reciprocal is one packed subtract + one packed multiply per axis,
+    // component-wise the reference's float operations
+    rtw_v2f bx, by, bz;
+    if (LDSB) { const rtw_l_v2* e = (rtw_l_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
+    else { const rtw_g_v2* e = (rtw_g_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
+    const rtw_v2f ox = { fr.o.x, fr.o.x }, oy = { fr.o.y, fr.o.y }, oz = { fr.o.z, fr.o.z };
+    const rtw_v2f vx = { fr.ix, fr.ix }, vy = { fr.iy, fr.iy }, vz = { fr.iz, fr.iz };
+    const rtw_v2f tx = (bx - ox) * vx, ty = (by - oy) * vy, tz = (bz - oz) * vz;
+    const float x1 = tx.x, x2 = tx.y, y1 = ty.x, y2 = ty.y, z1 = tz.x, z2 = tz.y;
     if (EXACT) {
         float tmin = -FLT_MAX, tmax = FLT_MAX;
         if (!fr.skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
@@ -255,11 +257,16 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     const bool prune = sc->prune != 0;
     // persistent waves: the grid holds a few blocks per CU and every wave takes tiles in turn, so that the gamma table
     // above and the launch of a wave are paid once per many tiles, not once per 64 pixels
-    const int n_tiles = p.count >> 6;
+    const int n_jobs = p.tile_order ? p.n_jobs : (p.count >> 6);
     const int wave0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-  for (int wk = wave0; wk < n_tiles; wk += nwaves) {
-    // tiles with the longest bin lists first (their waves take longest; the many empty tiles then fill the tail)
-    const int wt = p.tile_order ? (int)cldu(p.tile_order, wk) : wk;
+  for (int wk = wave0; wk < n_jobs; wk += nwaves) {
+    // Jobs in the order of the table: tiles with the longest bin lists first (their waves take longest; the many empty tiles
+    // then fill the tail).  A job is a tile (low 24 bits); with several sub-samples a long-listed tile is one job PER
+    // sub-sample (bits 24..27 = sub-sample + 1): four waves share its list walk, all its pixels are resolved by
+    // resolve_kernel from the kept sample colours.
+    const uint32_t job = p.tile_order ? cldu(p.tile_order, wk) : (uint32_t)wk;
+    const int wt = (int)(job & 0xFFFFFFu);
+    const int only_sample = (int)((job >> 24) & 15u) - 1;    // -1: this wave does every sub-sample of its tile
     const int wi = wt * 64 + lane_id();
     int px = 0, py = 0;
     const bool live = work_to_xy(p, wi, px, py);
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     f3 csum = mk(0, 0, 0);                                   // s[0] + s[1] + ... in sample order, as the reference adds them
     uint32_t queued = 0u;
     for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
+        if (only_sample >= 0 && i != only_sample) continue;
         PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)pass_of(p), (uint32_t)i);
         const Ray ray = camera_ray_xy(p, px, py, i, rng);
         if (STATS && live) ct.cams++;
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
             }
         }
         csum = csum + si;
-        if (live && near_wave && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
+        if (live && (near_wave || only_sample >= 0) && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
         if (queue_it) {                                      // the hit record waits under the path id; the queue entry follows below
             queued |= 1u << i;
             pb.hitrec[((size_t)wi * 4 + i) * 2] = hr0; pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = hr1;
@@ -392,11 +400,13 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     }
     // ONE atomic per wave for both lists (the two counters are one 64-bit word): the queue gets an entry per queued sample,
     // the pending list one per pixel with a queued sample
-    const bool pending = queued != 0u;
+    // a tile split by sub-sample: every pixel is pending (listed once, by the wave of sub-sample 0)
+    const bool pending = only_sample >= 0 ? live : queued != 0u;
+    const bool list_pixel = only_sample >= 0 ? (live && only_sample == 0) : pending;
     {
         const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
-                                 m3 = __ballot((queued & 8u) != 0u), mp = __ballot(pending);
-        if (mp != 0ull && !(p.pad_params & 8)) {
+                                 m3 = __ballot((queued & 8u) != 0u), mp = __ballot(list_pixel);
+        if ((mp | m0 | m1 | m2 | m3) != 0ull && !(p.pad_params & 8)) {
             const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
             unsigned long long base = 0ull;
             if (lane_id() == 0)
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
             if (queued & 2u) pb.queue[qb + c0 + (uint32_t)mbcnt(m1)] = (uint32_t)wi * 4u + 1u;
             if (queued & 4u) pb.queue[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = (uint32_t)wi * 4u + 2u;
             if (queued & 8u) pb.queue[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = (uint32_t)wi * 4u + 3u;
-            if (pending) pb.pend[pbase + (uint32_t)mbcnt(mp)] = (uint32_t)wi;
+            if (list_pixel) pb.pend[pbase + (uint32_t)mbcnt(mp)] = (uint32_t)wi;
         }
     }
     if (live && !pending) {

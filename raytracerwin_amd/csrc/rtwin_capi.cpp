@@ -115,7 +115,8 @@ struct rtw_scene {
     RtwSceneDev* d_scene = nullptr;
     std::vector<void*> allocs;
     // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
-    struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; const float* d_dx; const float* d_dy; const uint32_t* d_order; };
+    struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; const float* d_dx; const float* d_dy;
+                    const uint32_t* d_order[5]; int n_jobs[5]; };        // job tables per sub-sample count (index 1..4)
     std::vector<BinSet> bin_sets;
 };
 
@@ -556,7 +557,7 @@ int rtw_scene_mesh_flat(const rtw_scene* scene, int shape, int level, float* box
     const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
     const int n = m.flat_n[level] < max_entries ? m.flat_n[level] : max_entries;
     if (boxes6) for (int i = 0; i < n; i++) for (int c = 0; c < 6; c++)
-        boxes6[(size_t)i * 6 + c] = m.flat[level][(size_t)c * (size_t)m.flat_pad[level] + (size_t)i];
+        boxes6[(size_t)i * 6 + c] = m.flat[level][(size_t)i * 6 + (size_t)(c < 3 ? 2 * c : 2 * (c - 3) + 1)];
     return m.flat_n[level];
 }
 
@@ -750,16 +751,30 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
     const float aspect = (float)width / (float)height;
     for (int x = 0; x < width; x++) dx[(size_t)x] = -(float)(x - width / 2) / (width * 2) * aspect;
     for (int y = 0; y < height; y++) dy[(size_t)y] = -(float)(y - height / 2) / (height * 2);
-    // bins in order of decreasing list length (stable): the primary kernel of a full-frame launch takes its tiles in this order
-    std::vector<uint32_t> order(n_bins);
-    for (size_t b = 0; b < n_bins; b++) order[b] = (uint32_t)b;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
-    const RtwBinsDev* d = nullptr; const float* ddx = nullptr; const float* ddy = nullptr; const uint32_t* dord = nullptr;
+    // Job tables of a full-frame launch, one per sub-sample count: bins in order of decreasing list length (stable); with
+    // several sub-samples a bin with a long list becomes one job per sub-sample (sub-sample + 1 in bits 24..27).
+    std::vector<uint32_t> by_weight(n_bins);
+    for (size_t b = 0; b < n_bins; b++) by_weight[b] = (uint32_t)b;
+    std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    std::vector<uint32_t> order[5];
+    for (int spp = 1; spp <= 4; spp++) {
+        if (n_bins >= (1u << 24)) break;                    // tile numbers must fit 24 bits: no tables, tiles as numbered
+        for (uint32_t b : by_weight) {
+            if (spp > 1 && weight[b] >= 40u) for (int i = 0; i < spp; i++) order[spp].push_back(b | ((uint32_t)(i + 1) << 24));
+            else order[spp].push_back(b);
+        }
+    }
+    const RtwBinsDev* d = nullptr; const float* ddx = nullptr; const float* ddy = nullptr;
+    rtw_scene::BinSet bsnew; std::memset(&bsnew, 0, sizeof bsnew);
     int rc = upload(scene, h, &d); if (rc != RTW_OK) return rc;
-    if ((rc = upload(scene, order, &dord)) != RTW_OK) return rc;
+    for (int spp = 1; spp <= 4; spp++) {
+        if ((rc = upload(scene, order[spp], &bsnew.d_order[spp])) != RTW_OK) return rc;
+        bsnew.n_jobs[spp] = (int)order[spp].size();
+    }
     if ((rc = upload(scene, dx, &ddx)) != RTW_OK) return rc;
     if ((rc = upload(scene, dy, &ddy)) != RTW_OK) return rc;
-    scene->bin_sets.push_back({ width, height, bin_w, bin_h, const_cast<RtwBinsDev*>(d), ddx, ddy, dord });
+    bsnew.width = width; bsnew.height = height; bsnew.bin_w = bin_w; bsnew.bin_h = bin_h; bsnew.d_bins = const_cast<RtwBinsDev*>(d); bsnew.d_dx = ddx; bsnew.d_dy = ddy;
+    scene->bin_sets.push_back(bsnew);
     *out = &scene->bin_sets.back();
     return RTW_OK;
 }
@@ -816,7 +831,9 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         if (scene->traversal != 0 && scene->ctx->packets != 0 && choose_tiles(tiled) &&
             scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &bs) == RTW_OK) {
             p = tiled; p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
-            p.tile_order = (p.world <= 1 && p.row0 == 0 && p.nrows == p.height) ? bs->d_order : nullptr;
+            const bool full = p.world <= 1 && p.row0 == 0 && p.nrows == p.height && bs->d_order[sub_samples] != nullptr;
+            p.tile_order = full ? bs->d_order[sub_samples] : nullptr;
+            p.n_jobs = full ? bs->n_jobs[sub_samples] : 0;
             if (used_bins_pipeline) *used_bins_pipeline = true;
         } else {
             pipeline = 2;

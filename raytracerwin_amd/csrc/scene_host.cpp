@@ -426,7 +426,8 @@ void build_flat(HostMesh& m)
         m.flat[l].assign((size_t)6 * (size_t)m.flat_pad[l], 0.0f);
         n = (n + 15) / 16;
     }
-    auto at = [&](int l, int c, int i) -> float& { return m.flat[l][(size_t)c * (size_t)m.flat_pad[l] + (size_t)i]; };
+    // entry i of a level = six floats (min x, max x, min y, max y, min z, max z); c = 0..2 min x/y/z, 3..5 max x/y/z
+    auto at = [&](int l, int c, int i) -> float& { return m.flat[l][(size_t)i * 6 + (size_t)(c < 3 ? 2 * c : 2 * (c - 3) + 1)]; };
     for (const RtwNode& nd : m.nodes) {
         if (nd.tri < 0) continue;
         at(0, 0, nd.tri) = nd.min_x; at(0, 1, nd.tri) = nd.min_y; at(0, 2, nd.tri) = nd.min_z;
