@@ -61,10 +61,16 @@ __device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pa
     rtw_v2f bx, by, bz;
     if (LDSB) { const rtw_l_v2* e = (rtw_l_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
     else { const rtw_g_v2* e = (rtw_g_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
+#ifdef RTW_PACKED_BOX
     const rtw_v2f ox = { fr.o.x, fr.o.x }, oy = { fr.o.y, fr.o.y }, oz = { fr.o.z, fr.o.z };
     const rtw_v2f vx = { fr.ix, fr.ix }, vy = { fr.iy, fr.iy }, vz = { fr.iz, fr.iz };
     const rtw_v2f tx = (bx - ox) * vx, ty = (by - oy) * vy, tz = (bz - oz) * vz;
     const float x1 = tx.x, x2 = tx.y, y1 = ty.x, y2 = ty.y, z1 = tz.x, z2 = tz.y;
+#else
+    const float x1 = (bx.x - fr.o.x) * fr.ix, x2 = (bx.y - fr.o.x) * fr.ix;
+    const float y1 = (by.x - fr.o.y) * fr.iy, y2 = (by.y - fr.o.y) * fr.iy;
+    const float z1 = (bz.x - fr.o.z) * fr.iz, z2 = (bz.y - fr.o.z) * fr.iz;
+#endif
     if (EXACT) {
         float tmin = -FLT_MAX, tmax = FLT_MAX;
         if (!fr.skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
