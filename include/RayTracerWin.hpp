@@ -14,7 +14,10 @@
 // carrying rtw_last_error()) instead of being logged and ignored, and nothing here runs on the CPU.
 #pragma once
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <ctime>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -241,3 +244,65 @@ public:
         return rtw_png_save_argb(Filename.c_str(), Pixels, width, height) == RTW_OK;
     }
 };
+
+// ---- Src/RayTracerProgram.cpp:270-422 -----------------------------------------------------------------------------------------------
+// UpdateBitmapPixels: the base-colour preview pass, then TotalSamplesNum accumulated passes over the whole frame (the
+// reference's 10-row tasks are one rtw_render_passes call; after the first passes the library replays one launch graph
+// per pass), the reference's progress line per pass, cooperative quit, and the PNG written as
+// Output_<spp>spp_<date>.png into the first of SavedImages/, ../SavedImages/, ../../SavedImages/ that holds Output.txt.
+// Returns the path of the image written ("" if no output folder was found or the run was asked to stop before any pass).
+inline void FormatTimeString(char* Buffer, size_t Size, int TimeMs)          // Src/RayTracerProgram.cpp:242-268
+{
+    const int s = TimeMs / 1000, m = s / 60, h = m / 60;
+    if (h > 0) std::snprintf(Buffer, Size, "%dh %dm %ds", h, m % 60, s % 60);
+    else if (m > 0) std::snprintf(Buffer, Size, "%dm %ds", m, s % 60);
+    else std::snprintf(Buffer, Size, "%ds", s);
+}
+inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, ColorBuffer& Buffer, int TotalSamplesNum = 500, int MaxBounceTimes = 10,
+                                      const volatile bool* bQuit = nullptr, uint32_t Seed = 12345, bool LogEveryPass = true)
+{
+    const int NumTaskRows = 10;
+    // Draw base color for preview
+    RtwCheck(rtw_render_tasks(Scene.Get(), Buffer.Get(), NumTaskRows, 0, 1, MaxBounceTimes, 1, 0, 4, Seed));
+    Device.Synchronize();
+    const std::chrono::system_clock::time_point StartTime = std::chrono::system_clock::now();
+    std::chrono::system_clock::time_point LastFrameTime = StartTime;
+    int Done = 0;
+    for (int Sample = 0; Sample < TotalSamplesNum; Sample++) {
+        RtwCheck(rtw_render_passes(Scene.Get(), Buffer.Get(), NumTaskRows, 0, 1, MaxBounceTimes, 0, Sample, 1, 4, Seed));
+        Done = Sample + 1;
+        if (LogEveryPass || Sample + 1 == TotalSamplesNum) {
+            Device.Synchronize();
+            const std::chrono::system_clock::time_point CurrentTime = std::chrono::system_clock::now();
+            const int ElapsedTimeMs = (int)std::chrono::duration_cast<std::chrono::milliseconds>(CurrentTime - StartTime).count();
+            const int RemainingTimeMs = (int)((long long)ElapsedTimeMs / (Sample + 1) * (TotalSamplesNum - Sample - 1));
+            const int FrameTimeMs = (int)std::chrono::duration_cast<std::chrono::milliseconds>(CurrentTime - LastFrameTime).count();
+            char ElapsedTimeStr[64], RemainingTimeStr[64];
+            FormatTimeString(ElapsedTimeStr, sizeof ElapsedTimeStr, ElapsedTimeMs);
+            FormatTimeString(RemainingTimeStr, sizeof RemainingTimeStr, RemainingTimeMs);
+            std::printf("RayTracer - S: [%d/%d] | T: [%s / %s] | F: [%dms]\n", Sample + 1, TotalSamplesNum, ElapsedTimeStr, RemainingTimeStr, FrameTimeMs);
+            LastFrameTime = CurrentTime;
+        }
+        if (bQuit && *bQuit) break;
+    }
+    Device.Synchronize();
+    std::printf("Finished rendering image.\n");
+    if (Done == 0) return std::string();
+    char stamp[80];
+    const time_t rawtime = time(nullptr);
+    strftime(stamp, sizeof stamp, "%Y-%m-%d_%H-%M-%S", localtime(&rawtime));
+    std::string Filename = std::string("Output_") + std::to_string(TotalSamplesNum) + "spp_" + stamp + ".png";
+    std::string OutputPath("SavedImages/");
+    bool bFoundOutputFolder = false;
+    for (int i = 0; i < 3 && !bFoundOutputFolder; i++) {
+        std::FILE* f = std::fopen((OutputPath + "Output.txt").c_str(), "rb");
+        if (f) { std::fclose(f); bFoundOutputFolder = true; }
+        else OutputPath = std::string("../") + OutputPath;
+    }
+    if (!bFoundOutputFolder) { std::printf("Unable to find the output folder SavedImages!\n"); return std::string(); }
+    Filename = OutputPath + Filename;
+    const std::vector<Pixel> bitcolor = Buffer.bitcolor();
+    if (!RTexture::SaveBufferToPNG(Filename, bitcolor.data(), Buffer.bitmapWidth(), Buffer.bitmapHeight())) return std::string();
+    std::printf("Image saved as %s\n", Filename.c_str());
+    return Filename;
+}
