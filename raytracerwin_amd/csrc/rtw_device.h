@@ -32,6 +32,9 @@ struct PipelineTuning {
     int round_hint[32];    // wavefront: trace-list lengths of the previous pass per round, -1 = unknown
     int wave_stage;        // bins + wave pipeline: what pathwave_kernel's blocks stage in LDS for shape 0 (0 nothing .. 3 levels + triangles)
     size_t wave_stage_bytes;   // bytes of those arrays
+    // bins + wave pipeline: jobs [sky_job0, n_jobs) of the job table are sky-only tiles, rendered by primary_sky_kernel on aux_stream
+    // between the two events (fork after the previous work of the main stream, join before the pass ends); aux_stream null = one kernel
+    hipStream_t aux_stream; hipEvent_t fork_event, join_event; int sky_job0; const float* gamma_thr;
     bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
     int wave_blocks_mul;   // unstaged trace rounds: at most wave_blocks * 4 * wave_blocks_mul blocks of 4 waves (a wave takes rays in turn)
     int wave_tail;         // 1: after the first trace round one kernel finishes the frame (no launch per later bounce)

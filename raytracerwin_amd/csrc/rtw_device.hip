@@ -1787,7 +1787,22 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         if (want < resolve_blocks) resolve_blocks = want;
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
+    bool forked = false;
     if (p.wavefront == 2) {
+        RtwRenderParams ph = p;
+        if (tune.aux_stream && p.tile_order && tune.sky_job0 > 0 && tune.sky_job0 < p.n_jobs && !stats) {
+            // sky-only tiles on the second stream, beside everything else of this pass
+            forked = hipEventRecord(tune.fork_event, stream) == hipSuccess && hipStreamWaitEvent(tune.aux_stream, tune.fork_event, 0) == hipSuccess;
+            if (forked) {
+                const int sky_jobs = p.n_jobs - tune.sky_job0;
+                int sgrid = (sky_jobs + 3) / 4;
+                if (sgrid > tune.wave_blocks * tune.primary_blocks_per_cu) sgrid = tune.wave_blocks * tune.primary_blocks_per_cu;
+                hipLaunchKernelGGL(primary_sky_kernel, dim3(sgrid), dim3(block), 0, tune.aux_stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, p, tune.sky_job0);
+                (void)hipEventRecord(tune.join_event, tune.aux_stream);
+                ph.n_jobs = tune.sky_job0;
+            }
+        }
+        const RtwRenderParams& p = ph;      // the bins kernel takes the jobs the sky kernel does not
         const int jobs_grid = p.tile_order ? (p.n_jobs + 3) / 4 : grid;        // a wave per job (a tile, or a tile's sub-sample)
         const int pgrid = jobs_grid < tune.wave_blocks * tune.primary_blocks_per_cu ? jobs_grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // else waves take jobs in turn
         if (stats) hipLaunchKernelGGL(primary_bins_kernel<true>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
@@ -1955,6 +1970,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
     hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    if (forked) (void)hipStreamWaitEvent(stream, tune.join_event, 0);      // the pass is complete when both streams are
     if (tune.timing) (void)hipEventRecord(tune.timing[3], stream);
     return (int)hipGetLastError();
 }

@@ -248,6 +248,47 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
     }
 }
 
+// ---- tiles no leaf can be met from: sky only -----------------------------------------------------------------------------
+// The jobs [job0, n_jobs) of the job table are tiles whose bins are empty for every shape: each sample sees the sky
+// (Src/RayTracerScene.cpp:89-94).  A kernel of its own, launched beside primary_bins_kernel on a second stream: it needs a
+// fraction of that kernel's registers (no spills of scalar registers into vector lanes) and nothing later in the pass waits for it.
+__global__ __launch_bounds__(256) void primary_sky_kernel(const float* __restrict__ gamma_thr, float4* __restrict__ accum, uint32_t* __restrict__ argb,
+                                                          RtwRenderParams p, int job0)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = gamma_thr[threadIdx.x];
+    __syncthreads();
+    const int npix = p.width * p.height;
+    const uint32_t phase = table_phase(p.seed);
+    const int wave0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int wk = job0 + wave0; wk < p.n_jobs; wk += nwaves) {
+        const int wt = (int)(cldu(p.tile_order, wk) & 0xFFFFFFu);
+        const int wi = wt * 64 + lane_id();
+        int px = 0, py = 0;
+        const bool live = work_to_xy(p, wi, px, py);
+        if (!live) continue;
+        const int pixel = py * p.width + px;
+        float4 acc_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.preview) acc_prev = accum[pixel];
+        f3 csum = mk(0, 0, 0);
+        for (int i = 0; i < p.sub_samples; i++) {
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)i);
+            const Ray ray = camera_ray_xy(p, px, py, i, rng);
+            const f3 si = p.max_bounce != 0 ? sky_color(ray.d.y) : mk(0, 0, 0);       // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+            csum = csum + si;
+        }
+        const f3 c = p.sub_samples == 1 ? csum : csum / (float)p.sub_samples;
+        if (p.preview) {
+            argb[pixel] = pack_pixel(thr, c);
+        } else {
+            const f3 sum = mk(acc_prev.x, acc_prev.y, acc_prev.z) + c;
+            const int n = __float_as_int(acc_prev.w) + 1;
+            accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+            argb[pixel] = pack_pixel(thr, n == 1 ? sum : sum / (float)n);
+        }
+    }
+}
+
 // ---- primary rays through the screen bins ------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,

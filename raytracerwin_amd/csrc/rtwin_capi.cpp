@@ -58,6 +58,9 @@ struct rtw_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux_stream = nullptr;   // sky-only tiles of the bins + wave pipeline run here, beside the main stream
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
+    int sky_split = 1;                  // 0 = one primary kernel for every tile
     float* d_unit = nullptr;
     float* d_gamma = nullptr;
     float* d_lut = nullptr;
@@ -116,7 +119,7 @@ struct rtw_scene {
     std::vector<void*> allocs;
     // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
     struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; const float* d_dx; const float* d_dy;
-                    const uint32_t* d_order[5]; int n_jobs[5]; };        // job tables per sub-sample count (index 1..4)
+                    const uint32_t* d_order[5]; int n_jobs[5]; int n_busy[5]; };        // n_busy: jobs of tiles with a non-empty bin (they come first)        // job tables per sub-sample count (index 1..4)
     std::vector<BinSet> bin_sets;
 };
 
@@ -184,6 +187,9 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipMalloc((void**)&c->d_lut, sizeof lut));
     HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->h_pass, 64, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&c->d_pass, 64));
@@ -207,6 +213,9 @@ int rtw_context_destroy(rtw_context* ctx)
     if (ctx->pass_graph.graph) (void)hipGraphDestroy(ctx->pass_graph.graph);
     if (ctx->h_pass) (void)hipHostFree(ctx->h_pass);
     if (ctx->d_pass) (void)hipFree(ctx->d_pass);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->counters_event) (void)hipEventDestroy(ctx->counters_event);
     for (int i = 0; i < 4; i++) if (ctx->timing_events[i]) (void)hipEventDestroy(ctx->timing_events[i]);
@@ -239,6 +248,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     }
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
+    if (std::strcmp(name, "sky_split") == 0) { ctx->sky_split = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "use_graph") == 0) { ctx->use_graph = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "primary_blocks_per_cu") == 0) {
         if (value < 1 || value > 64) return fail(RTW_ERR_INVALID, "primary_blocks_per_cu must be 1..64");
@@ -757,11 +767,13 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
     for (size_t b = 0; b < n_bins; b++) by_weight[b] = (uint32_t)b;
     std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
     std::vector<uint32_t> order[5];
+    int n_busy[5] = { 0, 0, 0, 0, 0 };
     for (int spp = 1; spp <= 4; spp++) {
         if (n_bins >= (1u << 24)) break;                    // tile numbers must fit 24 bits: no tables, tiles as numbered
         for (uint32_t b : by_weight) {
             if (spp > 1 && weight[b] >= 40u) for (int i = 0; i < spp; i++) order[spp].push_back(b | ((uint32_t)(i + 1) << 24));
             else order[spp].push_back(b);
+            if (weight[b] > 0u) n_busy[spp] = (int)order[spp].size();
         }
     }
     const RtwBinsDev* d = nullptr; const float* ddx = nullptr; const float* ddy = nullptr;
@@ -770,6 +782,7 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
     for (int spp = 1; spp <= 4; spp++) {
         if ((rc = upload(scene, order[spp], &bsnew.d_order[spp])) != RTW_OK) return rc;
         bsnew.n_jobs[spp] = (int)order[spp].size();
+        bsnew.n_busy[spp] = n_busy[spp];
     }
     if ((rc = upload(scene, dx, &ddx)) != RTW_OK) return rc;
     if ((rc = upload(scene, dy, &ddy)) != RTW_OK) return rc;
@@ -825,6 +838,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     hipError_t e;
     // the bins + wave pipeline needs whole rows, the flat hierarchy (traversal != 0) and a frame that tiles; else pipeline 2
     int pipeline = scene->ctx->pipeline;
+    int sky_job0 = 0;
     if (pipeline == 3) {
         RtwRenderParams tiled = p;
         const rtw_scene::BinSet* bs = nullptr;
@@ -834,6 +848,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
             const bool full = p.world <= 1 && p.row0 == 0 && p.nrows == p.height && bs->d_order[sub_samples] != nullptr;
             p.tile_order = full ? bs->d_order[sub_samples] : nullptr;
             p.n_jobs = full ? bs->n_jobs[sub_samples] : 0;
+            sky_job0 = full ? bs->n_busy[sub_samples] : 0;
             if (used_bins_pipeline) *used_bins_pipeline = true;
         } else {
             pipeline = 2;
@@ -869,6 +884,8 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
         p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
         p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
+        tune.aux_stream = (cx->sky_split && !capturing) ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
+        tune.sky_job0 = sky_job0; tune.gamma_thr = cx->d_gamma;
         tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles

@@ -8,6 +8,7 @@
 // Src/Math.h:34-40).
 #include "rtw_host.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -451,8 +452,11 @@ void build_flat(HostMesh& m)
 // Screen-space bins of the reference's fixed camera.  Pixel (x, y), sub-sample offset (ox, oy) looks along
 // (dx + ox, dy + oy, -0.5) with dx = -(x - W/2) / (2W) * (W/H), dy = -(y - H/2) / (2H) (Src/RayTracerProgram.cpp:141-165),
 // so a point q (relative to the camera, q.z < 0) is seen at x = W/2 + H q.x / q.z, y = H/2 + H q.y / q.z (the offsets
-// move a sample by less than half a pixel).  A leaf joins every bin that its box's projected rectangle, grown by a
-// one-pixel margin, touches.  This only has to be a superset: the kernel still runs the reference's box test per ray.
+// move a sample by less than half a pixel).  A bin lists the leaves whose triangle a camera ray of the bin's pixels could
+// ACCEPT: the triangle faces the camera (the reference's own float test, identical for every camera ray) and its projection,
+// grown by a one-pixel margin, touches the bin (separating-axis test against the bin's rectangle).  A leaf left out would have
+// been box- or triangle-tested by the reference and rejected, which changes no result; the kernel still runs the reference's
+// box and triangle tests on every listed leaf, per ray.
 // ---------------------------------------------------------------------------------------
 bool build_bins(const HostMesh& m, int width, int height, int bin_w, int bin_h, std::vector<uint32_t>& off, std::vector<uint32_t>& ent)
 {
@@ -460,40 +464,76 @@ bool build_bins(const HostMesh& m, int width, int height, int bin_w, int bin_h, 
     if (width <= 0 || height <= 0 || bin_w <= 0 || bin_h <= 0 || width % bin_w != 0 || height % bin_h != 0) return false;
     const int bx = width / bin_w, by = height / bin_h;
     const double cx = (double)(width / 2), cy = (double)(height / 2), H = (double)height;
-    struct Rect { int node, x0, x1, y0, y1; };
-    std::vector<Rect> rects;
-    rects.reserve(m.tris.size());
+    const double margin = 1.0;
+    struct Item { int node, bin; };
+    std::vector<Item> items;
+    items.reserve(m.tris.size() * 4);
     for (size_t i = 0; i < m.nodes.size(); i++) {
         const RtwNode& nd = m.nodes[i];
         if (nd.tri < 0) continue;
         const double zmax = (double)nd.max_z - 7.0;
         if (!(zmax < -0.01)) return false;                      // not wholly in front of the camera: no bins for this mesh
-        double xa = 1e300, xb = -1e300, ya = 1e300, yb = -1e300;
-        for (int c = 0; c < 8; c++) {
-            const double qx = (double)((c & 1) ? nd.max_x : nd.min_x), qy = (double)((c & 2) ? nd.max_y : nd.min_y);
-            const double qz = (double)((c & 4) ? nd.max_z : nd.min_z) - 7.0;
-            const double sx = cx + H * qx / qz, sy = cy + H * qy / qz;
-            if (sx < xa) xa = sx; if (sx > xb) xb = sx;
-            if (sy < ya) ya = sy; if (sy > yb) yb = sy;
+        const RtwTri& t = m.tris[(size_t)nd.tri];
+        // Every camera ray starts at (0, 0, 7): the reference's first rejection, "origin behind the triangle's plane"
+        // (d2 = N.O - N.P0 < 0, Src/RRay.cpp:156-160), is the same float computation for all of them, so a triangle that
+        // fails it is accepted by no camera ray and needs no bin at all.
+        {
+            const float ox = 0.0f, oy = 0.0f, oz = 7.0f;
+            const float d0 = t.nx * ox + t.ny * oy + t.nz * oz;
+            const float d2 = d0 - t.d1;
+            if (d2 < 0) continue;
         }
-        if (!(xa == xa) || !(ya == ya)) return false;
-        const double margin = 1.0;
+        // the triangle's projection (an accepted hit lies inside the triangle, so its pixel lies inside this projection)
+        const double vx[3] = { t.p0x, t.p1x, t.p2x }, vy[3] = { t.p0y, t.p1y, t.p2y }, vz[3] = { t.p0z, t.p1z, t.p2z };
+        double sx[3], sy[3];
+        bool finite = true;
+        for (int k = 0; k < 3; k++) {
+            const double qz = vz[k] - 7.0;
+            sx[k] = cx + H * vx[k] / qz; sy[k] = cy + H * vy[k] / qz;
+            finite = finite && sx[k] == sx[k] && sy[k] == sy[k] && std::fabs(sx[k]) < 1e12 && std::fabs(sy[k]) < 1e12;
+        }
+        if (!finite) return false;
+        const double xa = std::min(sx[0], std::min(sx[1], sx[2])), xb = std::max(sx[0], std::max(sx[1], sx[2]));
+        const double ya = std::min(sy[0], std::min(sy[1], sy[2])), yb = std::max(sy[0], std::max(sy[1], sy[2]));
         double fx0 = std::floor(xa - margin), fx1 = std::ceil(xb + margin), fy0 = std::floor(ya - margin), fy1 = std::ceil(yb + margin);
         if (fx1 < 0 || fy1 < 0 || fx0 > width - 1 || fy0 > height - 1) continue;      // off screen
-        if (fx0 < 0) fx0 = 0; if (fy0 < 0) fy0 = 0;
-        if (fx1 > width - 1) fx1 = width - 1; if (fy1 > height - 1) fy1 = height - 1;
-        rects.push_back({ (int)i, (int)fx0 / bin_w, (int)fx1 / bin_w, (int)fy0 / bin_h, (int)fy1 / bin_h });
+        if (fx0 < 0) fx0 = 0;
+        if (fy0 < 0) fy0 = 0;
+        if (fx1 > width - 1) fx1 = width - 1;
+        if (fy1 > height - 1) fy1 = height - 1;
+        const int bx0 = (int)fx0 / bin_w, bx1 = (int)fx1 / bin_w, by0 = (int)fy0 / bin_h, by1 = (int)fy1 / bin_h;
+        // edges of the projected triangle with outward normals (skipped when the projection is degenerate)
+        const double area2 = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0]);
+        const double scale = std::fabs(xb - xa) + std::fabs(yb - ya) + 1.0;
+        const bool use_edges = std::fabs(area2) > 1e-9 * scale * scale;
+        for (int yb_ = by0; yb_ <= by1; yb_++) {
+            for (int xb_ = bx0; xb_ <= bx1; xb_++) {
+                bool separated = false;
+                if (use_edges) {
+                    // the bin's pixels, grown by the margin (a sample looks through a point less than half a pixel off its pixel)
+                    const double rx0 = (double)(xb_ * bin_w) - margin, rx1 = (double)(xb_ * bin_w + bin_w - 1) + margin;
+                    const double ry0 = (double)(yb_ * bin_h) - margin, ry1 = (double)(yb_ * bin_h + bin_h - 1) + margin;
+                    for (int e = 0; e < 3 && !separated; e++) {
+                        const int a = e, b2 = (e + 1) % 3, c = (e + 2) % 3;
+                        double nx = sy[b2] - sy[a], ny = -(sx[b2] - sx[a]);            // normal of edge a -> b
+                        if (nx * (sx[c] - sx[a]) + ny * (sy[c] - sy[a]) > 0) { nx = -nx; ny = -ny; }      // pointing away from the third vertex
+                        const double len = std::sqrt(nx * nx + ny * ny);
+                        if (!(len > 0)) continue;
+                        // the rectangle's corner that is deepest along -n: if even it is outside, the whole rectangle is
+                        const double px = nx > 0 ? rx0 : rx1, py = ny > 0 ? ry0 : ry1;
+                        if ((nx * (px - sx[a]) + ny * (py - sy[a])) / len > 1e-6) separated = true;
+                    }
+                }
+                if (!separated) items.push_back({ (int)i, yb_ * bx + xb_ });
+            }
+        }
     }
     off.assign((size_t)bx * (size_t)by + 1, 0u);
-    for (const Rect& r : rects)
-        for (int y = r.y0; y <= r.y1; y++)
-            for (int x = r.x0; x <= r.x1; x++) off[(size_t)y * (size_t)bx + (size_t)x + 1]++;
+    for (const Item& it : items) off[(size_t)it.bin + 1]++;
     for (size_t i = 1; i < off.size(); i++) off[i] += off[i - 1];
     ent.assign(off.back() ? off.back() : 1, 0u);
     std::vector<uint32_t> fill(off.begin(), off.end() - 1);
-    for (const Rect& r : rects)                                  // rects are in ascending node order, so every bin's list is too
-        for (int y = r.y0; y <= r.y1; y++)
-            for (int x = r.x0; x <= r.x1; x++) ent[fill[(size_t)y * (size_t)bx + (size_t)x]++] = (uint32_t)r.node;
+    for (const Item& it : items) ent[fill[(size_t)it.bin]++] = (uint32_t)it.node;       // items are in ascending node order, so every bin's list is too
     return true;
 }
 

@@ -201,10 +201,12 @@ def _camera_dirs(W, H, xs, ys, ox, oy):
 
 @pytest.mark.parametrize("name,W,H,bw,bh,step", [("TorusKnot", 192, 108, 16, 4, 3), ("TorusKnot", 96, 54, 32, 2, 1), ("TorusKnot", 128, 72, 64, 1, 2),
                                                  ("BlenderMonkey", 192, 108, 16, 4, 3), ("unitychan", 192, 108, 16, 4, 29)])
-def test_screen_bins_hold_every_leaf_a_camera_ray_can_meet(name, W, H, bw, bh, step):
-    """The bins only have to be a superset: for camera rays of every (sampled) pixel -- jitter corners, centre and random
-    offsets inside the sub-sample range -- every leaf whose box passes the reference's line test must be in the pixel's bin,
-    and every bin lists its leaves in ascending (= preorder) order."""
+def test_screen_bins_hold_every_triangle_a_camera_ray_can_accept(name, W, H, bw, bh, step):
+    """The bins only have to be a superset of what can be ACCEPTED: for camera rays of every (sampled) pixel -- jitter
+    corners, centre and random offsets inside the sub-sample range -- every front-facing triangle the ray passes through
+    (float64 ray / triangle test) must be in the pixel's bin; every bin lists leaves only, in ascending (= preorder) order.
+    (A leaf left out is one the reference would box- or triangle-test and reject: no result changes.)"""
+    g = np.load(os.path.join(GOLDEN, "mesh_%s.npz" % name))
     s = R.RayTracerScene(None)
     s.AddShape(R.RMeshShape.Create(asset(name + ".obj")))
     off, ent = s.mesh_bins(W, H, bw, bh)
@@ -214,7 +216,12 @@ def test_screen_bins_hold_every_leaf_a_camera_ray_can_meet(name, W, H, bw, bh, s
         e = ent[off[b]:off[b + 1]]
         assert (np.diff(e.astype(np.int64)) > 0).all() and (tri[e] >= 0).all()
     leaf_nodes = np.nonzero(tri >= 0)[0]
-    lo, hi = bounds[leaf_nodes, :3], bounds[leaf_nodes, 3:]
+    P = g["points"].reshape(-1, 3).astype(np.float64)
+    idx = g["pidx"].reshape(-1, 3)[tri[leaf_nodes]]
+    p0, p1, p2 = P[idx[:, 0]], P[idx[:, 1]], P[idx[:, 2]]
+    nrm = np.cross(p1 - p0, p2 - p0)
+    o = np.array([0, 0, 7.0])
+    facing = ((o - p0) * nrm).sum(1) > 1e-7 * np.maximum(1e-30, np.linalg.norm(nrm, axis=1))     # clearly in front of the plane
     nn = np.int64(len(bounds))
     keys = np.repeat(np.arange(len(off) - 1, dtype=np.int64), np.diff(off.astype(np.int64))) * nn + ent.astype(np.int64)     # (bin, leaf) pairs
     rng = np.random.default_rng(7)
@@ -223,19 +230,27 @@ def test_screen_bins_hold_every_leaf_a_camera_ray_can_meet(name, W, H, bw, bh, s
     xs, ys = pix % W, pix // W
     bins = ((ys // bh) * (W // bw) + xs // bw).astype(np.int64)
     offsets = [(-0.25, -0.25), (1.25, -0.25), (-0.25, 1.25), (1.25, 1.25), (0.5, 0.5)] + [tuple(rng.uniform(-0.25, 1.25, 2)) for _ in range(3)]
-    o = np.array([0, 0, 7], np.float32)
-    missing = 0
+    e1, e2 = p1 - p0, p2 - p0
+    missing, seen = 0, 0
     for fx, fy in offsets:
-        d = _camera_dirs(W, H, xs, ys, np.full(len(xs), fx * r), np.full(len(xs), fy * r))
-        inv = np.float32(1.0) / d
-        for c0 in range(0, len(xs), 2048):
-            sl = slice(c0, c0 + 2048)
-            t1 = (lo[None] - o) * inv[sl, None, :]
-            t2 = (hi[None] - o) * inv[sl, None, :]
-            hit = np.maximum(t1, t2).min(2) > np.minimum(t1, t2).max(2)       # RRay::TestIntersectionWithAabb, strict
+        d = _camera_dirs(W, H, xs, ys, np.full(len(xs), fx * r), np.full(len(xs), fy * r)).astype(np.float64)
+        for c0 in range(0, len(xs), 1024):
+            dd = d[c0:c0 + 1024]
+            # Moeller-Trumbore, rays (n, 1, 3) x triangles (1, m, 3)
+            pv = np.cross(dd[:, None, :], e2[None])
+            det = (e1[None] * pv).sum(2)
+            ok = np.abs(det) > 1e-14
+            inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+            tv = (o - p0)[None]
+            u = (tv * pv).sum(2) * inv
+            qv = np.cross(tv, e1[None])
+            v = (dd[:, None, :] * qv).sum(2) * inv
+            t = (e2[None] * qv).sum(2) * inv
+            hit = ok & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0) & facing[None]
             pi, li = np.nonzero(hit)
+            seen += len(pi)
             missing += int((~np.isin(bins[c0 + pi] * nn + leaf_nodes[li], keys)).sum())
-    assert missing == 0
+    assert seen > 0 and missing == 0
 
 
 def test_meshes_reaching_behind_the_camera_get_no_bins(tmp_path):
