@@ -181,8 +181,9 @@ int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int r
                      int max_bounce, int use_base_color, int pass_index, int sub_samples, uint32_t seed);
 /* UpdateBitmapPixels' sample loop (Src/RayTracerProgram.cpp:317-361): n_passes accumulated passes
  * first_pass .. first_pass + n_passes - 1 over this rank's tasks, as rtw_render_tasks would render
- * them one by one (same images).  After the first passes the library replays one captured launch
- * graph per pass, so a long progressive render is not bound by launch overhead. */
+ * them one by one (same images).  With the context option "use_graph" the library captures one pass
+ * as a launch graph (pass index on the device) and replays it per pass; measured on MI355X the passes
+ * are GPU-bound, so the default launches every pass kernel by kernel. */
 int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
                       int max_bounce, int use_base_color, int first_pass, int n_passes,
                       int sub_samples, uint32_t seed);

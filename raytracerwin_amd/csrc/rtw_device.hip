@@ -1463,24 +1463,105 @@ __global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __res
 // ======================================================================================================
 __device__ __forceinline__ const uint32_t* wf_list(const PipeBufs& pb, int which) { return which ? pb.tlist1 : pb.tlist0; }
 
+// direct slots (p.direct_slots): slot q = work item * sub_samples + sub-sample  <->  path id = work item * 4 + sub-sample
+__device__ __forceinline__ uint32_t slot_of_path(const RtwRenderParams& p, uint32_t wi, uint32_t sub) { return wi * (uint32_t)p.sub_samples + sub; }
+__device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32_t q)
+{
+    switch (p.sub_samples) {
+    case 1: return q * 4u;
+    case 2: return (q >> 1) * 4u + (q & 1u);
+    case 4: return q;
+    default: { const uint32_t wi = q / 3u; return wi * 4u + (q - wi * 3u); }
+    }
+}
+
+// RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94) for one path whose segment has just been traced: shade the
+// recorded hit (r0 = position + distance, r1 = shape + leaf slot; shape < 0 = the segment missed), push a level, set up
+// the next segment; or finish the path (fold the levels back in the reference's association order, write the radiance).
+// have_hit false: nothing to shade yet (the segment still has to be traced).  Returns true when the path goes on: its
+// state is then saved in slot q.
+template <bool STATS>
+__device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ sc, const PipeBufs& pb, const RtwRenderParams& p, uint32_t q, uint32_t pid,
+                                               Ray ray, PathRng rng, int depth, int nlev, bool have_hit, float4 r0, float4 r1, Counters& ct)
+{
+    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
+    if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
+    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
+    f3 L = mk(0, 0, 0);
+    bool done = false;
+    if (have_hit) {
+        const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
+        if (hs < 0) { L = sky_color(ray.d.y); done = true; }
+        else {
+            const RtwShapeDev& sh = sc->shapes[hs];
+            Hit h; int tri_index;
+            mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+            if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
+            else {
+                Ray out = ray;
+                if (p.preview) {
+                    const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
+                    L = mk(0, 0, 0) + pv.att * h.color; done = true;
+                } else {
+                    const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
+                    if (rng.random() <= h.alpha) {
+                        if (all_nonzero(b.att)) {
+                            lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
+                            lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                            lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+                            nlev++;
+                            ray = out;
+                        } else { L = mk(0, 0, 0) + b.em; done = true; }
+                    } else {
+                        lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+                        nlev++;
+                        const float rd = ray.dist - h.dist;
+                        ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
+                    }
+                    if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
+                }
+            }
+        }
+    }
+    if (done) {
+        for (int kk = nlev - 1; kk >= 0; kk--) {
+            const float4 a = lv.at(kk, 0);
+            if (__float_as_int(a.w) == 0) {
+                const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
+                L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
+            } else {
+                L = mk(0, 0, 0) + L;
+            }
+        }
+        pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+        return false;
+    }
+    pb.state[(size_t)q * 3] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
+    pb.state[(size_t)q * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
+    pb.state[(size_t)q * 3 + 2] = make_float4(__uint_as_float(rng.key), __uint_as_float(rng.table_reads),
+                                              __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
+    return true;
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
-    const uint32_t n = round == 0 ? pb.counters[0] : pb.counters[4 + round - 1];
-    const uint32_t* __restrict__ src = round == 0 ? nullptr : wf_list(pb, (round - 1) & 1);
+    // the round's input list: round 0 = the path queue itself; with direct slots the queue is round 0's TRACE list (round 1's input)
+    const bool from_queue = p.direct_slots && round == 1;
+    const uint32_t n = (round == 0 || from_queue) ? pb.counters[0] : pb.counters[4 + round - 1];
+    const uint32_t* __restrict__ src = round == 0 ? nullptr : (from_queue ? pb.queue : wf_list(pb, (round - 1) & 1));
     uint32_t* __restrict__ dst = round & 1 ? pb.tlist1 : pb.tlist0;
     const uint32_t nthreads = gridDim.x * blockDim.x;
     const int npix = p.width * p.height;
     const uint32_t phase = table_phase(p.seed);
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
     const uint32_t rounds_of_wave = (n + nthreads - 1) / nthreads;       // wave-uniform trip count: every lane joins the pushes
     for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < rounds_of_wave; it++, k += nthreads) {
         const bool live = k < n;
         const uint32_t q = live ? (round == 0 ? k : src[k]) : 0u;
         bool go_on = false;                                                // this path has another segment to trace
         if (live && q < pb.capacity) {
-            const uint32_t qe = pb.queue[q];
+            const uint32_t qe = p.direct_slots ? pid_of_slot(p, q) : pb.queue[q];
             const uint32_t pid = qe & 0x7FFFFFFFu;
             const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
             const int pixel = work_to_pixel(p, wi);
@@ -1499,65 +1580,13 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
                 nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
                 rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
             }
-            if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
-            LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
-            f3 L = mk(0, 0, 0);
-            bool done = false;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
             if (have_hit) {
                 // round 0 of the bins + wave pipeline: its primary kernel files hit records under the path id, not the slot
                 const size_t rec = (round == 0 && p.wavefront == 2) ? (size_t)pid : (size_t)q;
-                const float4 r0 = pb.hitslot[rec * 2], r1 = pb.hitslot[rec * 2 + 1];
-                const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
-                if (hs < 0) { L = sky_color(ray.d.y); done = true; }
-                else {
-                    const RtwShapeDev& sh = sc->shapes[hs];
-                    Hit h; int tri_index;
-                    mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
-                    if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
-                    else {
-                        Ray out = ray;
-                        if (p.preview) {
-                            const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
-                            L = mk(0, 0, 0) + pv.att * h.color; done = true;
-                        } else {
-                            const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
-                            if (rng.random() <= h.alpha) {
-                                if (all_nonzero(b.att)) {
-                                    lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
-                                    lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
-                                    lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
-                                    nlev++;
-                                    ray = out;
-                                } else { L = mk(0, 0, 0) + b.em; done = true; }
-                            } else {
-                                lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
-                                nlev++;
-                                const float rd = ray.dist - h.dist;
-                                ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
-                            }
-                            if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
-                        }
-                    }
-                }
+                r0 = pb.hitslot[rec * 2]; r1 = pb.hitslot[rec * 2 + 1];
             }
-            if (done) {
-                for (int kk = nlev - 1; kk >= 0; kk--) {
-                    const float4 a = lv.at(kk, 0);
-                    if (__float_as_int(a.w) == 0) {
-                        const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
-                        L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
-                    } else {
-                        L = mk(0, 0, 0) + L;
-                    }
-                }
-                pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
-            } else {
-                pb.state[(size_t)q * 3] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
-                pb.state[(size_t)q * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
-                pb.state[(size_t)q * 3 + 2] = make_float4(__uint_as_float(rng.key), __uint_as_float(rng.table_reads),
-                                                          __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
-                go_on = true;
-            }
+            go_on = shade_hit_step<STATS>(sc, pb, p, q, pid, ray, rng, depth, nlev, have_hit, r0, r1, ct);
         }
         wave_push(dst, &pb.counters[4 + round], go_on, q);
     }
@@ -1820,10 +1849,11 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         // shade(0), then trace(r) / shade(r + 1) for r = 0 .. max_bounce - 2: every queued path has a hit record, the last shade
         // step sees depth 0.  Trace rounds: a wave per ray, persistent blocks (one per CU when shape 0 is staged in LDS).
         auto items_of = [&](int round) {
+            if (p.direct_slots && round <= 1) return (long long)owners;      // the queue is round 0's trace list = round 1's input
             long long items = round == 0 ? owners : (tune.round_hint[round - 1] >= 0 ? (long long)tune.round_hint[round - 1] + tune.round_hint[round - 1] / 4 + 256 : owners);
             return items > owners ? (long long)owners : items;
         };
-        for (int r = 0; r < p.max_bounce; r++) {
+        for (int r = p.direct_slots ? 1 : 0; r < p.max_bounce; r++) {      // direct slots: the primary kernel was shade(0)
             if (r > 0) {
                 const long long rays = items_of(r);
                 const int stage = tune.wave_stage;

@@ -121,6 +121,9 @@ struct RtwRenderParams {
     int32_t row0, nrows;            // contiguous range: first screen row and number of rows; task partition: number of virtual rows
     int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
     int32_t pad_params;
+    int32_t direct_slots;           // bins + wave pipeline: the primary kernel shades the camera rays' hits itself; a path's slot in the
+                                    // dense arrays is work item * sub_samples + sub-sample (no queue), pb.queue is round 0's trace list
+    int32_t pad_direct;
     int32_t self_clean;             // resolve_kernel files the counters at word 64.. and zeroes them for the next pass
     int32_t n_jobs;                 // entries of tile_order
     const struct RtwBinsDev* bins;  // [n_shapes] or null

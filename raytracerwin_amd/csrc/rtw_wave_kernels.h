@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     }
     f3 csum = mk(0, 0, 0);                                   // s[0] + s[1] + ... in sample order, as the reference adds them
     uint32_t queued = 0u;
+    bool hit_any = false;                                    // some sample of this pixel hit something: the pixel is resolved later
     for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
         if (only_sample >= 0 && i != only_sample) continue;
         PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)pass_of(p), (uint32_t)i);
@@ -440,7 +441,12 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         }
         csum = csum + si;
         if (live && (near_wave || only_sample >= 0) && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
-        if (queue_it) {                                      // the hit record waits under the path id; the queue entry follows below
+        if (queue_it && p.direct_slots) {                    // shade the hit here: the path's slot needs no queue position
+            hit_any = true;
+            if (shade_hit_step<STATS>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, true, hr0, hr1, ct))
+                queued |= 1u << i;                           // it goes on: its slot joins round 0's trace list below
+        } else if (queue_it) {                               // the hit record waits under the path id; the queue entry follows below
+            hit_any = true;
             queued |= 1u << i;
             pb.hitrec[((size_t)wi * 4 + i) * 2] = hr0; pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = hr1;
         }
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     // ONE atomic per wave for both lists (the two counters are one 64-bit word): the queue gets an entry per queued sample,
     // the pending list one per pixel with a queued sample
     // a tile split by sub-sample: every pixel is pending (listed once, by the wave of sub-sample 0)
-    const bool pending = only_sample >= 0 ? live : queued != 0u;
+    const bool pending = only_sample >= 0 ? live : hit_any;
     const bool list_pixel = only_sample >= 0 ? (live && only_sample == 0) : pending;
     {
         const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
@@ -460,10 +466,12 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
                 base = atomicAdd(reinterpret_cast<unsigned long long*>(pb.counters), (unsigned long long)(c0 + c1 + c2 + c3) | ((unsigned long long)__popcll(mp) << 32));
             const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
             const uint32_t pbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
-            if (queued & 1u) pb.queue[qb + (uint32_t)mbcnt(m0)] = (uint32_t)wi * 4u;
-            if (queued & 2u) pb.queue[qb + c0 + (uint32_t)mbcnt(m1)] = (uint32_t)wi * 4u + 1u;
-            if (queued & 4u) pb.queue[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = (uint32_t)wi * 4u + 2u;
-            if (queued & 8u) pb.queue[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = (uint32_t)wi * 4u + 3u;
+            const uint32_t e0 = p.direct_slots ? slot_of_path(p, (uint32_t)wi, 0u) : (uint32_t)wi * 4u;     // a slot (round 0's trace list) or a path id (the queue)
+            const uint32_t es = 1u;
+            if (queued & 1u) pb.queue[qb + (uint32_t)mbcnt(m0)] = e0;
+            if (queued & 2u) pb.queue[qb + c0 + (uint32_t)mbcnt(m1)] = e0 + es;
+            if (queued & 4u) pb.queue[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = e0 + 2u * es;
+            if (queued & 8u) pb.queue[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = e0 + 3u * es;
             if (list_pixel) pb.pend[pbase + (uint32_t)mbcnt(mp)] = (uint32_t)wi;
         }
     }
@@ -518,11 +526,12 @@ template <bool STATS, int STAGE, int NT>
 __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
-    const uint32_t n = pb.counters[4 + round];
+    const bool from_queue = p.direct_slots && round == 0;       // with direct slots the path queue IS round 0's trace list
+    const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round];
     if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;         // (whole block) no ray left for this block's first wave
     uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
     const FlatSrc staged = stage_shape0<STAGE, NT>(sc, wave_dyn);
-    const uint32_t* __restrict__ src = wf_list(pb, round & 1);
+    const uint32_t* __restrict__ src = from_queue ? pb.queue : wf_list(pb, round & 1);
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
     const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);

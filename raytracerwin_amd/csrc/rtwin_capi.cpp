@@ -60,6 +60,7 @@ struct rtw_context {
     bool own_stream = false;
     hipStream_t aux_stream = nullptr;   // sky-only tiles of the bins + wave pipeline run here, beside the main stream
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    int direct_slots = 1;               // pipeline 3: the primary kernel shades the camera rays' hits itself (no shade(0) launch, no queue)
     int sky_split = 1;                  // 0 = one primary kernel for every tile
     float* d_unit = nullptr;
     float* d_gamma = nullptr;
@@ -98,7 +99,8 @@ struct rtw_context {
     int32_t* h_pass = nullptr;          // pinned staging word for d_pass
     int hint_period = 1;                // the queue lengths are read back every hint_period-th pass
     int hint_tick = 0;
-    int use_graph = 1;                  // rtw_render_passes: replay a captured pass (0 = launch every pass kernel by kernel)
+    int use_graph = 0;                  // rtw_render_passes: 1 = replay a captured pass as a launch graph (measured: no faster, the passes are GPU-bound,
+                                        // and a captured pass cannot use the second stream), 0 = launch every pass kernel by kernel
     int debug_primary = 0;              // timing experiments only (wrong images): 1 no gamma, 2 no accumulator traffic, 4 no bins loop
     int primary_blocks_per_cu = 64;     // pipeline 3: persistent primary kernel, blocks of 256 threads per CU
     int wave_tail = 0;                  // pipeline 3: 1 = after the first trace round one kernel finishes the frame (measured slower: register-bound)
@@ -248,6 +250,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     }
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
+    if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "sky_split") == 0) { ctx->sky_split = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "use_graph") == 0) { ctx->use_graph = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "primary_blocks_per_cu") == 0) {
@@ -915,6 +918,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         tune.path_variant = cx->path_variant;
         const size_t coff = rtw::pipeline_counters_offset(p.count, max_bounce);
         p.self_clean = p.wavefront == 2 ? 1 : 0;
+        p.direct_slots = (p.wavefront == 2 && cx->direct_slots && !cx->wave_fused && !cx->wave_tail) ? 1 : 0;
         tune.counters_clean = p.self_clean && cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
         cx->clean_ws = nullptr;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);

@@ -368,7 +368,7 @@ def test_render_passes_graph_replay_equals_pass_by_pass(ctx, mesh, ns, depth, wo
             s.render_passes(fb, 10, rank, world, depth, None, 8, 4, ns, 77)     # second call: continues the sequence
         a, b = fb.read_float(), fb.resolve_argb()
         assert (bits(a) == bits(ra)).all() and (b == rb).all(), graph
-    ctx.set_option("use_graph", 1)
+    ctx.set_option("use_graph", 0)
 
 
 @pytest.mark.gpu
