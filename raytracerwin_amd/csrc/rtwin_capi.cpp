@@ -120,8 +120,10 @@ struct rtw_scene {
     RtwSceneDev* d_scene = nullptr;
     std::vector<void*> allocs;
     // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
+    struct JobTable { int task_rows, rank, world, spp; const uint32_t* d_order; int n_jobs, n_busy; };     // n_busy: jobs of tiles with a non-empty bin (they come first)
     struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; const float* d_dx; const float* d_dy;
-                    const uint32_t* d_order[5]; int n_jobs[5]; int n_busy[5]; };        // n_busy: jobs of tiles with a non-empty bin (they come first)        // job tables per sub-sample count (index 1..4)
+                    std::vector<uint32_t> weight;           // per bin: leaves listed, over all shapes (1000+ for a shape without bins)
+                    std::vector<JobTable> jobs; };          // job tables per (task partition, sub-sample count) rendered so far
     std::vector<BinSet> bin_sets;
 };
 
@@ -743,9 +745,9 @@ int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb)
 }
 
 // Bins of every shape of the scene for one frame size and bin shape, built and uploaded on first use.
-static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bin_h, const rtw_scene::BinSet** out)
+static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bin_h, rtw_scene::BinSet** out)
 {
-    for (const rtw_scene::BinSet& b : scene->bin_sets)
+    for (rtw_scene::BinSet& b : scene->bin_sets)
         if (b.width == width && b.height == height && b.bin_w == bin_w && b.bin_h == bin_h) { *out = &b; return RTW_OK; }
     std::vector<RtwBinsDev> h(scene->meshes.size());
     const size_t n_bins = (size_t)(width / bin_w) * (size_t)(height / bin_h);
@@ -764,34 +766,58 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
     const float aspect = (float)width / (float)height;
     for (int x = 0; x < width; x++) dx[(size_t)x] = -(float)(x - width / 2) / (width * 2) * aspect;
     for (int y = 0; y < height; y++) dy[(size_t)y] = -(float)(y - height / 2) / (height * 2);
-    // Job tables of a full-frame launch, one per sub-sample count: bins in order of decreasing list length (stable); with
-    // several sub-samples a bin with a long list becomes one job per sub-sample (sub-sample + 1 in bits 24..27).
-    std::vector<uint32_t> by_weight(n_bins);
-    for (size_t b = 0; b < n_bins; b++) by_weight[b] = (uint32_t)b;
-    std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
-    std::vector<uint32_t> order[5];
-    int n_busy[5] = { 0, 0, 0, 0, 0 };
-    for (int spp = 1; spp <= 4; spp++) {
-        if (n_bins >= (1u << 24)) break;                    // tile numbers must fit 24 bits: no tables, tiles as numbered
-        for (uint32_t b : by_weight) {
-            if (spp > 1 && weight[b] >= 40u) for (int i = 0; i < spp; i++) order[spp].push_back(b | ((uint32_t)(i + 1) << 24));
-            else order[spp].push_back(b);
-            if (weight[b] > 0u) n_busy[spp] = (int)order[spp].size();
-        }
-    }
     const RtwBinsDev* d = nullptr; const float* ddx = nullptr; const float* ddy = nullptr;
-    rtw_scene::BinSet bsnew; std::memset(&bsnew, 0, sizeof bsnew);
+    rtw_scene::BinSet bsnew;
     int rc = upload(scene, h, &d); if (rc != RTW_OK) return rc;
-    for (int spp = 1; spp <= 4; spp++) {
-        if ((rc = upload(scene, order[spp], &bsnew.d_order[spp])) != RTW_OK) return rc;
-        bsnew.n_jobs[spp] = (int)order[spp].size();
-        bsnew.n_busy[spp] = n_busy[spp];
-    }
+    bsnew.weight = weight;
     if ((rc = upload(scene, dx, &ddx)) != RTW_OK) return rc;
     if ((rc = upload(scene, dy, &ddy)) != RTW_OK) return rc;
     bsnew.width = width; bsnew.height = height; bsnew.bin_w = bin_w; bsnew.bin_h = bin_h; bsnew.d_bins = const_cast<RtwBinsDev*>(d); bsnew.d_dx = ddx; bsnew.d_dy = ddy;
     scene->bin_sets.push_back(bsnew);
     *out = &scene->bin_sets.back();
+    return RTW_OK;
+}
+
+// Job table of one launch shape (p already tiled by choose_tiles): the launch's wave tiles in order of decreasing bin-list
+// length (stable), so that the waves that take longest start first and the sky-only tiles (no leaf listed: they come last and can
+// go to the lean sky kernel) fill the tail; with several sub-samples a tile with a long list is one job per sub-sample
+// (sub-sample + 1 in bits 24..27).  Built on the host on first use, cached per (task partition, sub-sample count).
+static int scene_job_table(rtw_scene* scene, rtw_scene::BinSet& bs, const RtwRenderParams& p, int spp, const rtw_scene::JobTable** out)
+{
+    *out = nullptr;
+    const bool linear = p.world <= 1;
+    if (linear && (p.row0 != 0 || p.nrows != p.height)) return RTW_OK;          // a partial range: tiles as numbered
+    const int key_rows = linear ? 0 : p.task_rows, key_rank = linear ? 0 : p.rank, key_world = linear ? 1 : p.world;
+    for (const rtw_scene::JobTable& t : bs.jobs)
+        if (t.task_rows == key_rows && t.rank == key_rank && t.world == key_world && t.spp == spp) { *out = &t; return RTW_OK; }
+    const int n_tiles = p.count >> 6;
+    if (n_tiles >= (1 << 24)) return RTW_OK;                                    // tile numbers must fit 24 bits
+    const int tiles_per_row = p.tiles_per_row;
+    std::vector<uint32_t> w((size_t)n_tiles, 0u);
+    for (int wt = 0; wt < n_tiles; wt++) {
+        const int band = wt / tiles_per_row, tx = wt - band * tiles_per_row;
+        const int vr = band * p.tile_h;
+        int y;
+        if (linear) y = p.row0 + vr;
+        else { const int j = vr / p.task_rows, r = vr - j * p.task_rows; y = (j * p.world + p.rank) * p.task_rows + r; }
+        if (vr >= p.nrows || y >= p.height) continue;                           // a dead tile (past the last task's rows)
+        w[(size_t)wt] = bs.weight[(size_t)(y / p.tile_h) * (size_t)tiles_per_row + (size_t)tx];
+    }
+    std::vector<uint32_t> by_weight((size_t)n_tiles);
+    for (int i = 0; i < n_tiles; i++) by_weight[(size_t)i] = (uint32_t)i;
+    std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+    std::vector<uint32_t> order;
+    int n_busy = 0;
+    for (uint32_t t : by_weight) {
+        if (spp > 1 && w[t] >= 40u) for (int i = 0; i < spp; i++) order.push_back(t | ((uint32_t)(i + 1) << 24));
+        else order.push_back(t);
+        if (w[t] > 0u) n_busy = (int)order.size();
+    }
+    rtw_scene::JobTable jt; jt.task_rows = key_rows; jt.rank = key_rank; jt.world = key_world; jt.spp = spp; jt.d_order = nullptr;
+    int rc = upload(scene, order, &jt.d_order); if (rc != RTW_OK) return rc;
+    jt.n_jobs = (int)order.size(); jt.n_busy = n_busy;
+    bs.jobs.push_back(jt);
+    *out = &bs.jobs.back();
     return RTW_OK;
 }
 
@@ -844,14 +870,15 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     int sky_job0 = 0;
     if (pipeline == 3) {
         RtwRenderParams tiled = p;
-        const rtw_scene::BinSet* bs = nullptr;
+        rtw_scene::BinSet* bs = nullptr;
         if (scene->traversal != 0 && scene->ctx->packets != 0 && choose_tiles(tiled) &&
             scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &bs) == RTW_OK) {
             p = tiled; p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
-            const bool full = p.world <= 1 && p.row0 == 0 && p.nrows == p.height && bs->d_order[sub_samples] != nullptr;
-            p.tile_order = full ? bs->d_order[sub_samples] : nullptr;
-            p.n_jobs = full ? bs->n_jobs[sub_samples] : 0;
-            sky_job0 = full ? bs->n_busy[sub_samples] : 0;
+            const rtw_scene::JobTable* jt = nullptr;
+            if (scene_job_table(scene, *bs, p, sub_samples, &jt) != RTW_OK) jt = nullptr;
+            p.tile_order = jt ? jt->d_order : nullptr;
+            p.n_jobs = jt ? jt->n_jobs : 0;
+            sky_job0 = jt ? jt->n_busy : 0;
             if (used_bins_pipeline) *used_bins_pipeline = true;
         } else {
             pipeline = 2;
