@@ -11,7 +11,7 @@
 #define __forceinline__ inline
 #define __restrict__
 #define __shared__ static thread_local
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = { x, y, z, w }; return r; }
 struct dim3e { unsigned x, y, z; };
@@ -24,6 +24,7 @@ static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); ret
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
 typedef void* hipStream_t;
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int min(int a, int b) { return a < b ? a : b; }
