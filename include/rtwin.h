@@ -80,14 +80,23 @@ int rtw_context_destroy(rtw_context* ctx);
 /* run every later launch of this context on the caller's hipStream_t (e.g. torch's) */
 int rtw_context_set_stream(rtw_context* ctx, void* hip_stream);
 int rtw_context_synchronize(rtw_context* ctx);
-/* tuning switches; results never depend on them.  "pipeline": 2 = primary / one shade + one trace
- * launch per bounce / resolve, 1 = primary / path / resolve launches, 0 = single kernel with one
- * thread per pixel.  "packets": 1 = camera rays are
- * traced as 64-ray packets inside the primary kernel (default).  "path_lanes": lanes per ray in the
- * path kernel, 4 (default) or 1. */
+/* Tuning switches; results never depend on them (every combination is tested bit-identical).
+ *   "pipeline"      3 (default) = screen bins for the camera rays (hits shaded in the same kernel, sky tiles in a
+ *                   second kernel on a side stream) + one wave-per-ray trace launch and one shade launch per bounce;
+ *                   2 = packet walk for camera rays + a 16-lanes-per-ray trace and a shade launch per bounce;
+ *                   1 = packet walk + one path kernel + resolve; 0 = one kernel, one thread per pixel.
+ *   pipeline 3:     "direct_slots" (1) camera-ray hits are shaded by the primary kernel; "sky_split" (1) sky-only tiles
+ *                   in their own kernel; "wave_stage" (0) LDS staging of shape 0 in the trace kernels, 1..3 = levels /
+ *                   leaves / triangles, -1 = as much as fits; "wave_fused" (0) one kernel carries the paths through all
+ *                   bounces; "wave_tail" (0) one kernel after the first trace round; "wave_paths", "wave_blocks_mul",
+ *                   "primary_blocks_per_cu": launch geometry; "use_graph" (0) rtw_render_passes replays a launch graph.
+ *   pipelines 1, 2: "packets" (1) camera rays traced as 64-ray packets inside the primary kernel; "path_lanes" lanes per
+ *                   ray in the path kernel: 16 (default), 4 or 1; "path_variant": occupancy variants of the path kernel.
+ *   "kernel_timing" 1 = record events around the stages of each pass (rtw_last_pass_kernel_ms);
+ *   "debug_primary" timing experiments only (skips work: wrong images). */
 int rtw_context_set_option(rtw_context* ctx, const char* name, int value);
-/* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's primary, path and resolve
- * kernels, measured on the context's stream; waits for that pass. */
+/* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's three stages -- primary kernel(s),
+ * the per-bounce trace / shade launches, resolve -- measured on the context's stream; waits for that pass. */
 int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3]);
 const char* rtw_last_error(void);
 const char* rtw_version(void);
@@ -135,8 +144,9 @@ int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int
 int rtw_scene_mesh_flat(const rtw_scene* scene, int shape, int level, float* boxes6, int max_entries);
 /* Screen-space bins of the reference's fixed camera (Src/RayTracerProgram.cpp:133-165) for a
  * width x height frame cut into bin_w x bin_h pixel bins: CSR offsets (bins + 1) and, per bin, the
- * node indices (ascending) of the leaves a camera ray of the bin's pixels can meet.  counts2 =
- * {number of offsets, number of entries}.  Returns 1, or 0 when this mesh gets no bins. */
+ * node indices (ascending) of the leaves whose triangle a camera ray of the bin's pixels could accept
+ * (it faces the camera by the reference's own float test and its projection touches the bin).
+ * counts2 = {number of offsets, number of entries}.  Returns 1, or 0 when this mesh gets no bins. */
 int rtw_scene_mesh_bins(const rtw_scene* scene, int shape, int width, int height, int bin_w, int bin_h,
                         uint32_t* offsets, int64_t max_offsets, uint32_t* entries, int64_t max_entries, int64_t* counts2);
 
