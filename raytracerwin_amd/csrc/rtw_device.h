@@ -36,6 +36,7 @@ struct PipelineTuning {
     // between the two events (fork after the previous work of the main stream, join before the pass ends); aux_stream null = one kernel
     hipStream_t aux_stream; hipEvent_t fork_event, join_event; int sky_job0; const float* gamma_thr;
     bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
+    int trace_block;       // threads per block of the unstaged trace kernel: 256 (default), 128 or 64
     int wave_blocks_mul;   // unstaged trace rounds: at most wave_blocks * 4 * wave_blocks_mul blocks of 4 waves (a wave takes rays in turn)
     int wave_tail;         // 1: after the first trace round one kernel finishes the frame (no launch per later bounce)
     int wave_fused;        // 1: pathwave_kernel carries the paths to their end, 0: one shade + one wave-per-ray trace launch per bounce

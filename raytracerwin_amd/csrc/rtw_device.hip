@@ -1868,7 +1868,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                     else { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<false, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
                         hipLaunchKernelGGL((trace_wave_kernel<false, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
                 } while (0)
-                if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
+                if (stage == 0 && tune.trace_block == 64) RTW_LAUNCH_TW(0, 64); else if (stage == 0 && tune.trace_block == 128) RTW_LAUNCH_TW(0, 128); else if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
 #undef RTW_LAUNCH_TW
             }
             if (r == 1 && tune.wave_tail && tune.wave_stage > 0) {

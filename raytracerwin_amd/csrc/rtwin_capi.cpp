@@ -83,6 +83,7 @@ struct rtw_context {
     int wave_stage = 0;                 // pipeline 3: LDS staging of shape 0 in the trace kernels: 0 = none (measured fastest: more waves in flight
                                         // beat LDS residency), 1..3 = levels / leaves / triangles, -1 = as much as fits
     int wave_blocks_mul = 8;
+    int trace_block = 128;              // measured: 128 / 64-thread blocks a little faster than 256 (fewer waves coupled to one block)
     const void* clean_ws = nullptr;     // workspace and counters offset whose counters the last pass left zeroed (bins + wave pipeline)
     size_t clean_off = 0;
     // a whole pass captured as a launch graph and replayed with the pass index on the device (rtw_render_passes)
@@ -244,6 +245,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         ctx->pipeline = value;
         return RTW_OK;
     }
+    if (std::strcmp(name, "trace_block") == 0) { ctx->trace_block = (value == 64 || value == 128) ? value : 256; return RTW_OK; }
     if (std::strcmp(name, "wave_blocks_mul") == 0) { ctx->wave_blocks_mul = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_stage") == 0) {
         if (value < -1 || value > 3) return fail(RTW_ERR_INVALID, "wave_stage must be -1 (automatic) or 0..3");
@@ -916,7 +918,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
         tune.aux_stream = (cx->sky_split && !capturing) ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
         tune.sky_job0 = sky_job0; tune.gamma_thr = cx->d_gamma;
-        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
+        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.trace_block = cx->trace_block; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
             const rtw::HostMesh& m0 = *scene->meshes[0];
