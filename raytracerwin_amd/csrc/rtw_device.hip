@@ -1794,7 +1794,6 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     hipError_t e = hipSuccess;
     if (!tune.counters_clean) e = hipMemsetAsync(pb.counters, 0, 256, stream);     // else: the previous pass's resolve_kernel left them zeroed
     if (e != hipSuccess) return (int)e;
-    if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "memset -> %s (wavefront %d packets %d)\n", hipGetErrorString(hipPeekAtLastError()), p.wavefront, p.packets);
     pb.hitslot = pb.hitrec; pb.state = nullptr; pb.tlist0 = pb.tlist1 = nullptr; pb.capacity = 0;
     if (p.wavefront) {
         pb.state = (float4*)(w + l.wf_state_off); pb.tlist0 = (uint32_t*)(w + l.wf_tlist0_off); pb.tlist1 = (uint32_t*)(w + l.wf_tlist1_off);
@@ -1843,7 +1842,6 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         if (stats) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     }
-    if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "primary -> %s\n", hipGetErrorString(hipPeekAtLastError()));
     if (tune.timing) (void)hipEventRecord(tune.timing[1], stream);
     if (p.wavefront == 2 && !tune.wave_fused) {
         // shade(0), then trace(r) / shade(r + 1) for r = 0 .. max_bounce - 2: every queued path has a hit record, the last shade
@@ -1944,12 +1942,10 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                 const int tb = size_for(r, 16);
                 if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
                 else hipLaunchKernelGGL(trace_kernel<false>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
-                if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "trace round %d blocks %d -> %s\n", r - 1, tb, hipGetErrorString(hipPeekAtLastError()));
             }
             const int sb = size_for(r, 1);
             if (stats) hipLaunchKernelGGL(shade_kernel<true>, dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
             else hipLaunchKernelGGL(shade_kernel<false>, dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
-            if (getenv("RTW_DEBUG_LAUNCH")) fprintf(stderr, "shade round %d blocks %d -> %s\n", r, sb, hipGetErrorString(hipPeekAtLastError()));
         }
     } else if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
         constexpr int NT = 256;         // experiment: no register cap (2 waves/SIMD), staged tree per 4 waves

@@ -320,6 +320,7 @@ int rtw_scene_destroy(rtw_scene* scene)
     if (scene->ctx) {
         (void)hipSetDevice(scene->ctx->device);
         (void)hipStreamSynchronize(scene->ctx->stream);
+        if (scene->ctx->pass_graph.scene == scene) scene->ctx->pass_graph.valid = false;      // a captured pass holds this scene's device pointers
     }
     for (void* p : scene->allocs) (void)hipFree(p);
     delete scene;
@@ -703,6 +704,7 @@ int rtw_framebuffer_wrap(rtw_context* ctx, int width, int height, void* accum_de
 int rtw_framebuffer_destroy(rtw_framebuffer* fb)
 {
     if (!fb) return RTW_OK;
+    if (fb->ctx && fb->ctx->pass_graph.fb == fb) fb->ctx->pass_graph.valid = false;
     if (fb->owned) {
         (void)hipSetDevice(fb->ctx->device);
         (void)hipStreamSynchronize(fb->ctx->stream);
