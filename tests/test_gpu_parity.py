@@ -313,6 +313,8 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
         ctx.set_option("wave_fused", 1 if fused == 1 else 0)         # fused: 1 = one kernel for all bounces, 2 = one kernel after the first trace round
         ctx.set_option("wave_tail", 1 if fused == 2 else 0)
         ctx.set_option("wave_stage", stage)
+        ctx.set_option("direct_slots", 0 if (mode == 3 and stage == 1) else 1)       # the stage-1 run also takes the queue + shade(0) route
+        ctx.set_option("sky_split", 0 if (mode == 3 and stage == 0) else 1)          # the stage-0 run also keeps every tile in one primary kernel
         ctx.stats_enable(True)
         ctx.stats_reset()
         a, b = render_frame(ctx, s, W, H, ns, depth, preview, 4321, 0, 2)
@@ -323,7 +325,9 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     ctx.set_option("path_lanes", 16)
     ctx.set_option("wave_fused", 0)
     ctx.set_option("wave_tail", 0)
-    ctx.set_option("wave_stage", -1)
+    ctx.set_option("wave_stage", 0)
+    ctx.set_option("direct_slots", 1)
+    ctx.set_option("sky_split", 1)
     keys = ("rays", "shaded_hits", "tex_samples", "camera_rays")     # box / triangle test counts depend on the walk
     for o in out[1:]:
         assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
