@@ -990,7 +990,12 @@ __device__ __forceinline__ Bounce material_eval(const RtwSceneDev* __restrict__ 
 // j = 1: sampled colour, j = 2: emissive.
 struct LevelStore {
     float4* __restrict__ ws; size_t stride; size_t tid;
-    __device__ __forceinline__ float4& at(int level, int j) const { return ws[((size_t)level * 3 + (size_t)j) * stride + tid]; }
+    int rec_levels;     // 0: structure of arrays over the launch's threads (coalesced); > 0: one record of rec_levels x 3 float4 per
+                        // path slot (the slots of the per-bounce pipeline are sparse: a path's levels then share cache lines / pages)
+    __device__ __forceinline__ float4& at(int level, int j) const
+    {
+        return rec_levels > 0 ? ws[(tid * (size_t)rec_levels + (size_t)level) * 3 + (size_t)j] : ws[((size_t)level * 3 + (size_t)j) * stride + tid];
+    }
 };
 
 template <bool STATS, int LPR, bool LDSQ>
@@ -1210,7 +1215,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     if (pixel < npix) {
         const uint32_t phase = table_phase(p.seed);
-        LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi;
+        LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi; lv.rec_levels = 0;
         f3 c = mk(0, 0, 0);
         for (int i = 0; i < p.sub_samples; i++) {
             PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)i);
@@ -1417,7 +1422,7 @@ __global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __res
     const int npix = p.width * p.height;
     const uint32_t phase = table_phase(p.seed);
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nowners; lv.tid = (size_t)go;
+    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nowners; lv.tid = (size_t)go; lv.rec_levels = 0;
     for (uint32_t q = go; q < n; q += nowners) {
         const uint32_t qe = pb.queue[q];
         const uint32_t pid = qe & 0x7FFFFFFFu;
@@ -1486,7 +1491,7 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
 {
     TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
     if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
-    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
+    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
     f3 L = mk(0, 0, 0);
     bool done = false;
     if (have_hit) {
@@ -1718,7 +1723,7 @@ __global__ __launch_bounds__(256) void ray_trace_kernel(const RtwSceneDev* __res
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     const uint32_t pixel = keys2[i * 2], sample = keys2[i * 2 + 1];
     PathRng rng; rng_init(rng, seed, table_phase(seed), npix, pixel, sample / 4u, sample % 4u);
-    LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)i;
+    LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)i; lv.rec_levels = 0;
     const f3 c = trace_path<STATS, 1, false>(sc, tc, r, max_bounce, preview != 0, rng, ct, lv);
     rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
     if (STATS) flush_counters(sc, ct);

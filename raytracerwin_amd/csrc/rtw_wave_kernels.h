@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
             have_hit = true;
             r0 = pb.hitslot[(size_t)q * 2]; r1 = pb.hitslot[(size_t)q * 2 + 1];
         }
-        LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q;
+        LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
         for (;;) {
             bool need_trace = false;
             if (alive) {
