@@ -464,7 +464,10 @@ bool build_bins(const HostMesh& m, int width, int height, int bin_w, int bin_h, 
     if (width <= 0 || height <= 0 || bin_w <= 0 || bin_h <= 0 || width % bin_w != 0 || height % bin_h != 0) return false;
     const int bx = width / bin_w, by = height / bin_h;
     const double cx = (double)(width / 2), cy = (double)(height / 2), H = (double)height;
-    const double margin = 1.0;
+    // A sub-sample looks through a point up to 1.25 / (4 W) off its pixel centre in dx and dy (Src/RayTracerProgram.cpp:147-162), i.e.
+    // 1.25 H / (2 W) PIXELS (a pixel is 1 / (2 H) wide in those units): under half a pixel for landscape frames, several pixels for tall
+    // narrow ones.  The margin covers that plus a pixel of slack.
+    const double margin = 1.0 + 1.25 * (double)height / (2.0 * (double)width);
     struct Item { int node, bin; };
     std::vector<Item> items;
     items.reserve(m.tris.size() * 4);

@@ -392,3 +392,18 @@ def test_config5_shape_4k_depth8_pipelines_agree_and_tasks_compose(ctx):
         s.render_tasks(fb, 10, rank, 8, 8, None, 3, 4, 2024)
     a8, b8 = fb.read_float(), fb.resolve_argb()
     assert (bits(a8) == bits(a3)).all() and (b8 == b3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,W,H,ns,depth", [("unitychan", 64, 200, 4, 5), ("BlenderMonkey", 64, 600, 4, 4), ("TorusKnot", 64, 450, 2, 2),
+                                               ("BlenderMonkey", 48, 1000, 3, 3), ("TorusKnot", 1000, 48, 4, 3), ("unitychan", 37, 211, 4, 2)])
+def test_tall_narrow_and_odd_frames_bins_equal_single_kernel(ctx, mesh, W, H, ns, depth):
+    """The sub-sample jitter is 1 / (4 W) in camera units whatever the height (Src/RayTracerProgram.cpp:147-162), so on a tall
+    narrow frame it spans several PIXELS; the screen bins' margin has to follow it.  Frames of such shapes (and sizes no tile
+    shape divides) through the bins + wave pipeline equal the one-thread-per-pixel kernel."""
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.8, 0.7)))
+    ctx.set_option("pipeline", 0)
+    a0, b0 = render_frame(ctx, s, W, H, ns, depth, 0, 555, 1, 2)
+    ctx.set_option("pipeline", 3)
+    a3, b3 = render_frame(ctx, s, W, H, ns, depth, 0, 555, 1, 2)
+    assert (bits(a0) == bits(a3)).all() and (b0 == b3).all()

@@ -200,7 +200,8 @@ def _camera_dirs(W, H, xs, ys, ox, oy):
 
 
 @pytest.mark.parametrize("name,W,H,bw,bh,step", [("TorusKnot", 192, 108, 16, 4, 3), ("TorusKnot", 96, 54, 32, 2, 1), ("TorusKnot", 128, 72, 64, 1, 2),
-                                                 ("BlenderMonkey", 192, 108, 16, 4, 3), ("unitychan", 192, 108, 16, 4, 29)])
+                                                 ("BlenderMonkey", 192, 108, 16, 4, 3), ("unitychan", 192, 108, 16, 4, 29),
+                                                 ("TorusKnot", 64, 200, 16, 4, 1), ("BlenderMonkey", 64, 600, 16, 4, 3)])
 def test_screen_bins_hold_every_triangle_a_camera_ray_can_accept(name, W, H, bw, bh, step):
     """The bins only have to be a superset of what can be ACCEPTED: for camera rays of every (sampled) pixel -- jitter
     corners, centre and random offsets inside the sub-sample range -- every front-facing triangle the ray passes through
