@@ -407,3 +407,17 @@ def test_tall_narrow_and_odd_frames_bins_equal_single_kernel(ctx, mesh, W, H, ns
     ctx.set_option("pipeline", 3)
     a3, b3 = render_frame(ctx, s, W, H, ns, depth, 0, 555, 1, 2)
     assert (bits(a0) == bits(a3)).all() and (b0 == b3).all()
+
+
+@pytest.mark.gpu
+def test_randomised_scenes_frames_and_options_bins_equal_single_kernel(ctx):
+    """tools/soak.py: 60 random cases (OBJ assets, two-mesh scenes, triangle soups with degenerate / axis-aligned / coincident /
+    behind-the-camera triangles; random material trees, frame shapes, spp, depth, rank splits and pipeline options) through the
+    one-thread-per-pixel kernel and through the bins + wave pipeline: same bits."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rtw_soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    bad = mod.run(20261004, 60, ctx, lambda *a, **k: lines.append(" ".join(str(x) for x in a)))
+    assert bad == 0, [ln for ln in lines if ln.endswith("DIFF")]

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the render pipelines (test infrastructure, needs a GPU).
+
+  python tools/soak.py [--seed S] [--cases N]
+
+Every case draws a scene (one of the three OBJ assets, two of them together, or a random triangle soup with degenerate,
+axis-aligned, coincident and behind-the-camera triangles), a material tree, a frame shape (including tall / narrow / odd sizes),
+spp, depth, preview flag, passes, a rank split and random pipeline options, renders it through the one-thread-per-pixel kernel
+(pipeline 0, the most literal reading of ThreadWorker_Render, Src/RayTracerProgram.cpp:130-189) and through the default bins + wave
+pipeline, and compares accumulator and ARGB bits.  Prints one line per case and the number of mismatches; exit code 1 on any."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import raytracerwin_amd as R  # noqa: E402
+
+
+def soup(rng, kind):
+    n = int(rng.choice([1, 2, 7, 33, 200, 1500]))
+    ctr = rng.uniform(-2.0, 2.0, (n, 1, 3)).astype(np.float32)
+    if kind == "behind":                 # some triangles at or behind the camera plane z = 7: no screen bins for the shape
+        ctr[:, 0, 2] = rng.uniform(-2.0, 9.0, n)
+    tri = ctr + rng.normal(0, rng.choice([0.05, 0.4, 2.0]), (n, 3, 3)).astype(np.float32)
+    if kind == "flat":                   # axis-aligned sheets: zero-thickness leaf boxes
+        tri[:, :, int(rng.integers(0, 3))] = np.round(ctr[:, :, int(rng.integers(0, 3))] * 2) / 2
+    if kind == "degenerate" and n > 2:
+        tri[::3, 2] = tri[::3, 1]        # zero-area
+        tri[1::5] = tri[0]               # coincident copies
+    pts = tri.reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    nrm = rng.normal(0, 1, (3 * n, 3)).astype(np.float32)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-6)
+    tcs = rng.uniform(0, 1, (3 * n, 3)).astype(np.float32)
+    return R.RMeshShape.FromArrays(pts, tcs, nrm, idx, idx, idx)
+
+
+def material(rng, depth=0):
+    k = int(rng.integers(0, 7 if depth < 2 else 4))
+    col = tuple(float(v) for v in rng.uniform(0.2, 1.0, 3))
+    if k == 0:
+        return R.SurfaceMaterial_Diffuse(col)
+    if k == 1:
+        return R.SurfaceMaterial_DiffuseChecker(col, float(rng.choice([0.5, 2.0, 5.0])))
+    if k == 2:
+        return R.SurfaceMaterial_Reflective(col, 0.0)
+    if k == 3:
+        return R.SurfaceMaterial_Emissive(col)
+    if k == 4:
+        return R.SurfaceMaterial_Blend(material(rng, depth + 1), material(rng, depth + 1), float(rng.choice([0.0, 0.3, 0.5, 1.0])))
+    if k == 5:
+        return R.SurfaceMaterial_Combine(material(rng, depth + 1), material(rng, depth + 1))
+    return R.SurfaceMaterial_Null()
+
+
+def run(seed_arg, cases, ctx=None, log=print):
+    rng = np.random.default_rng(seed_arg)
+    ctx = ctx or R.Context(0)
+    objs = ("TorusKnot", "BlenderMonkey", "unitychan")
+    bad = 0
+    for it in range(cases):
+        kind = str(rng.choice(["obj", "obj", "obj", "two", "soup", "flat", "degenerate", "behind"]))
+        s = R.RayTracerScene(ctx)
+        if kind in ("obj", "two"):
+            for m in rng.choice(objs, 2 if kind == "two" else 1, replace=False):
+                s.AddShape(R.RMeshShape.Create(os.path.join(ROOT, "assets", "%s.obj" % m)), material(rng) if rng.random() < 0.8 else None)
+        else:
+            s.AddShape(soup(rng, kind), material(rng))
+            if rng.random() < 0.3:
+                s.AddShape(soup(rng, "soup"), material(rng))
+        s.commit()
+        W = int(rng.choice([1, 7, 16, 37, 48, 64, 96, 100, 128, 160, 200, 256, 333, 384, 512, 640, 1024, 1920]))
+        H = int(rng.choice([1, 5, 36, 54, 64, 90, 100, 108, 128, 211, 256, 360, 450, 600, 1080]))
+        spp, depth = int(rng.integers(1, 5)), int(rng.integers(0, 9))
+        prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 4))
+        world, rows = int(rng.choice([1, 1, 2, 3, 8])), int(rng.choice([10, 10, 7, 16, 1]))
+        opts = dict(direct_slots=int(rng.random() < 0.8), sky_split=int(rng.random() < 0.8), wave_stage=int(rng.choice([0, 0, 0, 1, 2, 3, -1])),
+                    trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3))
+        res = []
+        for pl in (0, 3):
+            ctx.set_option("pipeline", pl)
+            for k, v in opts.items():
+                ctx.set_option(k, v if pl == 3 else dict(direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0)[k])
+            fb = R.Framebuffer(ctx, W, H)
+            for rank in range(world):
+                if pl == 3 and opts["use_graph"]:
+                    s.render_passes(fb, rows, rank, world, depth, R.RenderOption(bool(prev)), 0, npass, spp, seed)
+                else:
+                    for p in range(npass):
+                        s.render_tasks(fb, rows, rank, world, depth, R.RenderOption(bool(prev)), p, spp, seed)
+            res.append((fb.read_float().view(np.uint32).copy(), fb.resolve_argb().copy()))
+            fb.close()
+        s.close()
+        ok = bool((res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all())
+        bad += not ok
+        log(it, kind, W, H, "spp", spp, "d", depth, "prev", prev, "passes", npass, "world", world, "rows", rows, opts, "OK" if ok else "DIFF", flush=True)
+    for k, v in dict(pipeline=3, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0).items():
+        ctx.set_option(k, v)
+    log("soak done, seed", seed_arg, "mismatches:", bad)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=60)
+    a = ap.parse_args()
+    return 1 if run(a.seed, a.cases) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
