@@ -111,6 +111,30 @@ class Scene:
                     self.set_texture(s, m, px)
         return s
 
+    def add_sphere(self, center, radius):
+        return lib().orc_scene_add_sphere(self.h, _p(np.asarray(center, np.float32)), C.c_float(radius))
+
+    def add_plane(self, normal, point):
+        return lib().orc_scene_add_plane(self.h, _p(np.asarray(normal, np.float32)), _p(np.asarray(point, np.float32)))
+
+    def add_capsule(self, start, end, radius):
+        return lib().orc_scene_add_capsule(self.h, _p(np.asarray(start, np.float32)), _p(np.asarray(end, np.float32)), C.c_float(radius))
+
+    def add_shapes(self, scene, asset_path):
+        """scene: a list from tests/scenes.py; asset_path(name) -> OBJ path"""
+        for sh in scene:
+            if sh[0] == "sphere":
+                i = self.add_sphere(sh[1], sh[2])
+            elif sh[0] == "plane":
+                i = self.add_plane(sh[1], sh[2])
+            elif sh[0] == "capsule":
+                i = self.add_capsule(sh[1], sh[2], sh[3])
+            else:
+                i = self.add_mesh_obj(asset_path(sh[1]))
+            if sh[-1] is not None:
+                self.set_material(i, sh[-1])
+        return self
+
     def texture_path(self, shape, mat):
         buf = C.create_string_buffer(8192)
         lib().orc_mesh_texture_path(self.h, shape, mat, buf, 8192)

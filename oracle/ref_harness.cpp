@@ -173,15 +173,54 @@ static std::vector<orc_material_node> load_material(const char* path)
 
 static RayTracerProgram* g_program = nullptr;
 static RMeshShape* g_mesh = nullptr;
+static bool g_scene_file = false;
+
+static std::unique_ptr<ISurfaceMaterial> material_arg(const char* matfile, bool dash_is_diffuse)
+{
+    if (matfile && strcmp(matfile, "none") == 0) return std::unique_ptr<ISurfaceMaterial>();
+    if (matfile && strcmp(matfile, "-") != 0) return build_material(load_material(matfile), 0);
+    if (!dash_is_diffuse) return std::unique_ptr<ISurfaceMaterial>();
+    return std::unique_ptr<ISurfaceMaterial>(new SurfaceMaterial_Diffuse(RVec3(1, 1, 1)));
+}
+
+// A ".scene" file lists the shapes in insertion order, one per line (numbers are decimal renderings of exact floats):
+//   sphere cx cy cz r MAT | plane nx ny nz px py pz MAT | capsule sx sy sz ex ey ez r MAT | mesh OBJ MAT
+// MAT = a material-node file, "-" (Diffuse(1,1,1)) or "none" (no material).  The shapes are made by the reference's own
+// RSphere / RPlane / RCapsule / RMeshShape::Create and added with RayTracerScene::AddShape.
+static void setup_scene_file(const char* path)
+{
+    FILE* f = fopen(path, "r");
+    if (!f) { fprintf(stderr, "harness: cannot read %s\n", path); exit(2); }
+    char kind[32], a[4096], m[4096];
+    while (fscanf(f, "%31s", kind) == 1) {
+        double v[7];
+        if (!strcmp(kind, "sphere")) {
+            if (fscanf(f, "%lf %lf %lf %lf %4095s", &v[0], &v[1], &v[2], &v[3], m) != 5) exit(2);
+            g_program->GetScene()->AddShape(RSphere::Create(RVec3((float)v[0], (float)v[1], (float)v[2]), (float)v[3]), material_arg(m, true));
+        } else if (!strcmp(kind, "plane")) {
+            if (fscanf(f, "%lf %lf %lf %lf %lf %lf %4095s", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], m) != 7) exit(2);
+            g_program->GetScene()->AddShape(RPlane::Create(RVec3((float)v[0], (float)v[1], (float)v[2]), RVec3((float)v[3], (float)v[4], (float)v[5])), material_arg(m, true));
+        } else if (!strcmp(kind, "capsule")) {
+            if (fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %4095s", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], m) != 8) exit(2);
+            g_program->GetScene()->AddShape(RCapsule::Create(RVec3((float)v[0], (float)v[1], (float)v[2]), RVec3((float)v[3], (float)v[4], (float)v[5]), (float)v[6]), material_arg(m, true));
+        } else if (!strcmp(kind, "mesh")) {
+            if (fscanf(f, "%4095s %4095s", a, m) != 2) exit(2);
+            auto mesh = RMeshShape::Create(a);
+            g_mesh = mesh.get();
+            g_program->GetScene()->AddShape(std::move(mesh), material_arg(m, true));
+        } else { fprintf(stderr, "harness: bad scene line '%s'\n", kind); exit(2); }
+    }
+    fclose(f);
+}
+
 static void setup_scene(const char* obj, const char* matfile)
 {
     g_program = new RayTracerProgram();       // sets CurrentInstance; no window is opened
+    const size_t L = strlen(obj);
+    if (L > 6 && strcmp(obj + L - 6, ".scene") == 0) { g_scene_file = true; setup_scene_file(obj); return; }
     auto mesh = RMeshShape::Create(obj);
     g_mesh = mesh.get();
-    std::unique_ptr<ISurfaceMaterial> mat;
-    if (matfile && strcmp(matfile, "-") != 0) mat = build_material(load_material(matfile), 0);
-    else mat = std::unique_ptr<ISurfaceMaterial>(new SurfaceMaterial_Diffuse(RVec3(1, 1, 1)));
-    g_program->GetScene()->AddShape(std::move(mesh), std::move(mat));
+    g_program->GetScene()->AddShape(std::move(mesh), material_arg(matfile, true));
 }
 
 static void dump_tree(const KdNode* n, std::vector<float>& bounds, std::vector<int>& tri)
@@ -286,7 +325,8 @@ int main(int argc, char** argv)
             RayHitResult h;
             int s = g_program->GetScene()->FindIntersectionWithScene(r, h);
             int tri = -1;
-            if (s >= 0) {   // same query again, straight at the tree, to learn the triangle index
+            if (g_scene_file) tri = -2;     // several shapes: the triangle index is not recorded
+            else if (s >= 0) {   // same query again, straight at the tree, to learn the triangle index
                 RayHitResult h2;
                 g_mesh->Spatial->TestRayIntersection(r, g_mesh->Points.data(), &h2, &tri);
             }

@@ -418,6 +418,9 @@ typedef struct {
 typedef struct {
     aabb_t aabb;            /* RShape::Aabb */
     int has_culling_bounds;
+    int kind;               /* ORC_SHAPE_* */
+    vec3 a, b;              /* sphere: a = Center; plane: a = Normal, b = Point; capsule: a = Start, b = End (Src/Shapes.h:46-112) */
+    float radius;
     mesh_t* mesh;
     material_t material;
     int has_material;
@@ -657,7 +660,129 @@ static int mesh_test_ray(const mesh_t* m, const ray_t* in_ray, hit_t* out, int* 
 /* ------------------------------------------------------------------------- */
 static const float BounceRayStartOffset = 0.0001f;   /* Src/SurfaceMaterials.cpp:13 */
 
-/* FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) */
+/* RAabb::ExpandBySphere (Src/RAabb.h:46-54) */
+static inline void aabb_expand_by_sphere(aabb_t* b, vec3 c, float r)
+{
+    if (c.x - r < b->pmin.x) b->pmin.x = c.x - r;
+    if (c.y - r < b->pmin.y) b->pmin.y = c.y - r;
+    if (c.z - r < b->pmin.z) b->pmin.z = c.z - r;
+    if (c.x + r > b->pmax.x) b->pmax.x = c.x + r;
+    if (c.y + r > b->pmax.y) b->pmax.y = c.y + r;
+    if (c.z + r > b->pmax.z) b->pmax.z = c.z + r;
+}
+
+/* RRay::TestIntersectionWithSphere (Src/RRay.cpp:25-66): quadratic in the parameter of Origin + t * (Direction * Distance).
+ * Writes position, normal and distance only -- the sampled colour / alpha of `result` stay what they were. */
+static int ray_test_sphere(const ray_t* r, vec3 c, float radius, hit_t* result)
+{
+    float dx = r->dir.x * r->distance;
+    float dy = r->dir.y * r->distance;
+    float dz = r->dir.z * r->distance;
+    vec3 o = r->origin;
+    float qa = dx * dx + dy * dy + dz * dz;
+    float qb = 2 * dx * (o.x - c.x) + 2 * dy * (o.y - c.y) + 2 * dz * (o.z - c.z);
+    float qc = c.x * c.x + c.y * c.y + c.z * c.z + o.x * o.x + o.y * o.y + o.z * o.z +
+               -2 * (c.x * o.x + c.y * o.y + c.z * o.z) - radius * radius;
+    float d = qb * qb - 4 * qa * qc;
+    if (d >= 0) {
+        float t = (-qb - sqrtf(d)) / (qa * 2);
+        if (t <= 0) return 0;
+        vec3 hp = v3(o.x + t * dx, o.y + t * dy, o.z + t * dz);
+        float dist = v3mag(v3sub(hp, o));
+        if (dist > r->distance) return 0;
+        if (result) {
+            result->pos = hp;
+            result->normal = v3normalized(v3sub(hp, c));
+            result->distance = dist;
+        }
+        return 1;
+    }
+    return 0;
+}
+
+/* RRay::TestIntersectionWithPlane (Src/RRay.cpp:68-87); `fabsf(denom) > 1e-6` compares against a double constant */
+static int ray_test_plane(const ray_t* r, vec3 n, vec3 p, hit_t* result)
+{
+    float denom = v3dot(n, r->dir);
+    if ((double)fabsf(denom) > 1e-6) {
+        vec3 p0l0 = v3sub(p, r->origin);
+        float t = v3dot(p0l0, n) / denom;
+        if (t >= 0 && t < r->distance) {
+            if (result) {
+                result->pos = v3add(r->origin, v3muls(r->dir, t));
+                result->normal = n;
+                result->distance = t;
+            }
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* RCapsule::TestRayCylinderIntersection (Src/Shapes.cpp:64-125); `fabs(a) < FLT_EPSILON` is the double overload on a float */
+static int ray_test_cylinder(const ray_t* r, vec3 start, vec3 end, float radius, hit_t* result)
+{
+    vec3 d = v3sub(end, start);
+    vec3 m = v3sub(r->origin, start);
+    float dd = v3dot(d, d);
+    float nd = v3dot(r->dir, d);
+    float mn = v3dot(m, r->dir);
+    float md = v3dot(m, d);
+    float mm = v3dot(m, m);
+    if (v3dot(v3sub(r->origin, start), v3sub(end, start)) < 0 && v3dot(r->dir, v3sub(end, start)) < 0) return 0;
+    if (v3dot(v3sub(r->origin, end), v3sub(start, end)) < 0 && v3dot(r->dir, v3sub(start, end)) < 0) return 0;
+    float a = dd - nd * nd;
+    float b = dd * mn - nd * md;
+    float c = dd * (mm - radius * radius) - md * md;
+    if (fabs((double)a) < (double)FLT_EPSILON) return 0;
+    if ((b * b - a * c) < 0) return 0;
+    float rt = (-b - sqrtf(b * b - a * c)) / a;
+    if (rt < 0) return 0;
+    vec3 v = v3add(r->origin, v3muls(r->dir, rt));
+    if (v3dot(v3sub(v, start), v3sub(end, start)) < 0) return 0;
+    if (v3dot(v3sub(v, end), v3sub(start, end)) < 0) return 0;
+    if (result) {
+        result->distance = rt;
+        result->pos = v3add(r->origin, v3muls(r->dir, rt));
+        vec3 side = v3cross(v3sub(end, start), v3sub(result->pos, start));
+        result->normal = v3normalized(v3cross(side, v3sub(end, start)));
+    }
+    return 1;
+}
+
+/* RCapsule::TestRayIntersection (Src/Shapes.cpp:34-62): the side first; failing that the two end spheres into fresh
+ * RayHitResults, the nearer (the second on a tie) copied WHOLE into *OutResult -- which resets its sampled colour / alpha. */
+static int ray_test_capsule(const ray_t* r, vec3 start, vec3 end, float radius, hit_t* result)
+{
+    if (!ray_test_cylinder(r, start, end, radius, result)) {
+        hit_t r1, r2; hit_init(&r1); hit_init(&r2);
+        int b1 = ray_test_sphere(r, start, radius, &r1);
+        int b2 = ray_test_sphere(r, end, radius, &r2);
+        if (result) {
+            if (b1 && b2) *result = r1.distance < r2.distance ? r1 : r2;
+            else if (b1) *result = r1;
+            else if (b2) *result = r2;
+        }
+        return b1 || b2;
+    }
+    return 1;
+}
+
+static int shape_test_ray(const shape_t* s, const ray_t* r, hit_t* out, int* tri_out)
+{
+    switch (s->kind) {
+    case ORC_SHAPE_MESH: return s->mesh ? mesh_test_ray(s->mesh, r, out, tri_out) : 0;
+    case ORC_SHAPE_SPHERE: if (!ray_test_sphere(r, s->a, s->radius, out)) return 0; break;
+    case ORC_SHAPE_PLANE: if (!ray_test_plane(r, s->a, s->b, out)) return 0; break;
+    case ORC_SHAPE_CAPSULE: if (!ray_test_capsule(r, s->a, s->b, s->radius, out)) return 0; break;
+    default: return 0;
+    }
+    if (tri_out) *tri_out = -1;     /* (this API's convention: no triangle index for an analytic shape) */
+    return 1;
+}
+
+/* FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125).  ONE RayHitResult serves all shapes: a sphere, plane or capsule
+ * side that hits after a textured mesh did keeps the mesh hit's sampled colour and alpha. */
 static int find_intersection(const orc_scene* sc, ray_t test_ray, hit_t* out, int* tri_out)
 {
     int hit_shape = -1;
@@ -665,7 +790,7 @@ static int find_intersection(const orc_scene* sc, ray_t test_ray, hit_t* out, in
     for (int i = 0; i < sc->n_shapes; i++) {
         const shape_t* s = &sc->shapes[i];
         if (!s->has_culling_bounds || ray_test_aabb(&test_ray, &s->aabb)) {
-            int hit = s->mesh ? mesh_test_ray(s->mesh, &test_ray, out, tri_out) : 0;
+            int hit = shape_test_ray(s, &test_ray, out, tri_out);
             if (hit) { test_ray.distance = out->distance; hit_shape = i; }
         }
     }
@@ -1053,6 +1178,37 @@ int orc_scene_add_mesh_obj(orc_scene* sc, const char* obj_path)
     sc->shapes = (shape_t*)realloc(sc->shapes, sizeof(shape_t) * (size_t)(sc->n_shapes + 1));
     sc->shapes[sc->n_shapes] = s;
     return sc->n_shapes++;
+}
+static int scene_push_shape(orc_scene* sc, const shape_t* s)
+{
+    sc->shapes = (shape_t*)realloc(sc->shapes, sizeof(shape_t) * (size_t)(sc->n_shapes + 1));
+    sc->shapes[sc->n_shapes] = *s;
+    return sc->n_shapes++;
+}
+/* RSphere / RPlane / RCapsule constructors (Src/Shapes.h:46-112) */
+int orc_scene_add_sphere(orc_scene* sc, const float center[3], float radius)
+{
+    shape_t s; memset(&s, 0, sizeof s);
+    aabb_init(&s.aabb); s.has_culling_bounds = 1; s.kind = ORC_SHAPE_SPHERE;
+    s.a = v3(center[0], center[1], center[2]); s.radius = radius;
+    aabb_expand_by_sphere(&s.aabb, s.a, radius);
+    return scene_push_shape(sc, &s);
+}
+int orc_scene_add_plane(orc_scene* sc, const float normal[3], const float point[3])
+{
+    shape_t s; memset(&s, 0, sizeof s);
+    aabb_init(&s.aabb); s.has_culling_bounds = 0; s.kind = ORC_SHAPE_PLANE;      /* RPlane::HasCullingBounds (Src/Shapes.cpp:28-32) */
+    s.a = v3(normal[0], normal[1], normal[2]); s.b = v3(point[0], point[1], point[2]);
+    return scene_push_shape(sc, &s);
+}
+int orc_scene_add_capsule(orc_scene* sc, const float start[3], const float end[3], float radius)
+{
+    shape_t s; memset(&s, 0, sizeof s);
+    aabb_init(&s.aabb); s.has_culling_bounds = 1; s.kind = ORC_SHAPE_CAPSULE;
+    s.a = v3(start[0], start[1], start[2]); s.b = v3(end[0], end[1], end[2]); s.radius = radius;
+    aabb_expand_by_sphere(&s.aabb, s.a, radius);
+    aabb_expand_by_sphere(&s.aabb, s.b, radius);
+    return scene_push_shape(sc, &s);
 }
 int orc_scene_set_material(orc_scene* sc, int shape, const orc_material_node* nodes, int n)
 {

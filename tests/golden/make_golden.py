@@ -19,6 +19,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes as SC  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 ASSETS = os.path.join(ROOT, "assets")
@@ -138,11 +140,76 @@ def golden_raytrace(tag, name, mat, n, depth, seed, W, Hh, tmp, rng, bounds):
                         rgb=np.fromfile(op, np.float32).reshape(-1, 3))
 
 
+def write_scene_file(scene, tmp, tag):
+    """the harness's .scene text: shapes in insertion order, numbers as exact decimal renderings of the float32 values"""
+    num = lambda v: " ".join("%.17g" % float(np.float32(x)) for x in (v if isinstance(v, (tuple, list)) else [v]))  # noqa: E731
+    lines = []
+    for k, sh in enumerate(scene):
+        if sh[-1] is None:
+            mat = "none"
+        else:
+            mat = os.path.join(tmp, "%s_mat%d.bin" % (tag, k))
+            O.materials(sh[-1]).tofile(mat)
+        if sh[0] == "sphere":
+            lines.append("sphere %s %s %s" % (num(sh[1]), num(sh[2]), mat))
+        elif sh[0] == "plane":
+            lines.append("plane %s %s %s" % (num(sh[1]), num(sh[2]), mat))
+        elif sh[0] == "capsule":
+            lines.append("capsule %s %s %s %s" % (num(sh[1]), num(sh[2]), num(sh[3]), mat))
+        else:
+            lines.append("mesh %s %s" % (obj_path(sh[1]), mat))
+    path = os.path.join(tmp, tag + ".scene")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return path
+
+
+def golden_scene_closest(tag, n, tmp, rng, mesh_bounds):
+    scene = SC.SCENES[tag]()
+    sp = write_scene_file(scene, tmp, tag)
+    rays = make_rays(SC.scene_bounds(scene, mesh_bounds), n, rng)
+    rp, hp = os.path.join(tmp, "rays.bin"), os.path.join(tmp, "hits.bin")
+    rays.tofile(rp)
+    run(["closest", sp, rp, len(rays), hp])
+    r = np.fromfile(hp, np.float32).reshape(-1, 13)
+    np.savez_compressed(os.path.join(OUT, "sceneclosest_%s.npz" % tag), scene=tag, rays=rays, hit=r[:, :11].copy(),
+                        shape=r[:, 11].copy().view(np.int32))
+
+
+def golden_scene_frame(name, tag, W, Hh, ns, depth, preview, seed, pass0, npass, tmp):
+    sp, fp = write_scene_file(SC.SCENES[tag](), tmp, tag), os.path.join(tmp, "frame")
+    run(["frame", sp, "-", W, Hh, ns, depth, preview, seed, pass0, npass, 0, W * Hh - 1, fp])
+    np.savez_compressed(os.path.join(OUT, "sceneframe_%s.npz" % name), scene=tag,
+                        params=np.array([W, Hh, ns, depth, preview, seed, pass0, npass], np.int64),
+                        accum=np.fromfile(fp + ".accum.f32", np.float32).reshape(-1, 4),
+                        argb=np.fromfile(fp + ".argb.u32", np.uint32))
+
+
+def main_scenes(tmp, rng, bounds):
+    """multi-shape scenes: RSphere / RPlane / RCapsule beside meshes (tests/scenes.py)"""
+    for tag in ("default_nofuzz", "quirk", "shapes"):
+        golden_scene_closest(tag, 700, tmp, rng, bounds)
+    S = golden_scene_frame
+    S("default_d5", "default", 80, 80, 4, 5, 0, 12345, 0, 1, tmp)
+    S("default_nofuzz_d5", "default_nofuzz", 80, 80, 4, 5, 0, 12345, 0, 2, tmp)
+    S("default_preview", "default", 80, 80, 4, 5, 1, 12345, 0, 1, tmp)
+    S("quirk_d4", "quirk", 96, 96, 4, 4, 0, 77, 0, 1, tmp)
+    S("quirk_preview", "quirk", 96, 96, 4, 4, 1, 77, 0, 1, tmp)
+    S("shapes_d6", "shapes", 96, 64, 4, 6, 0, 9, 1, 2, tmp)
+    S("shapes_1spp_d2", "shapes", 50, 70, 1, 2, 0, 9, 0, 1, tmp)
+
+
 def main():
     O.build()
     if not os.path.exists(H):
         sys.exit("oracle/_ref/ref_harness is not built (no /root/reference here?)")
     rng = np.random.default_rng(20261004)
+    if "--scenes-only" in sys.argv:        # add the multi-shape fixtures without regenerating the others
+        rng = np.random.default_rng(20261005)
+        with tempfile.TemporaryDirectory() as tmp:
+            bounds = {n: np.load(os.path.join(OUT, "mesh_%s.npz" % n))["shape_bounds"] for n in ("TorusKnot", "BlenderMonkey", "unitychan")}
+            main_scenes(tmp, rng, bounds)
+        return
     with tempfile.TemporaryDirectory() as tmp:
         bounds = {}
         for name in ("TorusKnot", "BlenderMonkey", "unitychan"):
@@ -167,6 +234,7 @@ def main():
         F("unitychan_preview", "unitychan", "diffuse", 96, 96, 4, 4, 1, 12345, 0, 1, tmp)
         golden_raytrace("unitychan_diffuse", "unitychan", "diffuse", 500, 6, 4242, 1920, 1080, tmp, rng, bounds["unitychan"])
         golden_raytrace("monkey_blendfuzz", "BlenderMonkey", "blendfuzz", 900, 6, 4242, 1920, 1080, tmp, rng, bounds["BlenderMonkey"])
+        main_scenes(tmp, np.random.default_rng(20261005), bounds)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("golden fixtures written: %.2f MB" % (total / 1e6))
 

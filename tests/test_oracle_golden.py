@@ -130,3 +130,49 @@ def test_pool_equals_serial(oracle_mod):
     s.render_pass_pool(b, 4, False, 0, 4, 11, threads=4, task_rows=10)
     (aa, ab), (ba, bb) = a.read(), b.read()
     assert (bits(aa) == bits(ba)).all() and (ab == bb).all()
+
+
+# ---- multi-shape scenes: RSphere / RPlane / RCapsule beside meshes (tests/scenes.py) ----------------------------------
+import scenes as SC  # noqa: E402
+
+_multi = {}
+
+
+def multi_scene(O, tag):
+    if tag not in _multi:
+        _multi[tag] = O.Scene().add_shapes(SC.SCENES[tag](), lambda n: asset(n + ".obj"))
+    return _multi[tag]
+
+
+@pytest.mark.parametrize("tag", ["default_nofuzz", "quirk", "shapes"])
+def test_scene_closest_hit_matches_reference(oracle_mod, tag):
+    """FindIntersectionWithScene over spheres, planes, capsules and meshes in insertion order (Src/RayTracerScene.cpp:99-125),
+    including the sampled colour a nearer analytic hit inherits from an earlier textured-mesh hit."""
+    g = np.load(os.path.join(GOLDEN, "sceneclosest_%s.npz" % tag))
+    hf, hs, _ = multi_scene(oracle_mod, tag).trace_closest(g["rays"])
+    assert (hs == g["shape"]).all()
+    hit = hs >= 0
+    assert hit.sum() > 100 and len(set(hs[hit].tolist())) >= 3
+    assert (bits(hf[hit]) == bits(g["hit"][hit])).all()
+    # misses too: whatever a failed query left in the result
+    assert (bits(hf) == bits(g["hit"])).all()
+    if tag == "quirk":      # the quirk fires: analytic-shape hits whose sampled colour is not the default white
+        analytic = hit & (hs > 0)
+        assert (np.abs(hf[analytic, 7:10] - 1.0).max(axis=1) > 1e-3).sum() > 20
+
+
+@pytest.mark.parametrize("name", ["default_d5", "default_nofuzz_d5", "default_preview", "quirk_d4", "quirk_preview", "shapes_d6",
+                                  "shapes_1spp_d2"])
+def test_scene_frame_matches_reference(oracle_mod, name):
+    """RayTracerProgram::SetupScene's scene (Src/RayTracerProgram.cpp:467-552) and two synthetic multi-shape scenes, rendered by
+    the reference's RayTrace through the harness: the oracle gives the same accumulator and ARGB bits."""
+    g = np.load(os.path.join(GOLDEN, "sceneframe_%s.npz" % name))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    s = multi_scene(oracle_mod, str(g["scene"]))
+    fb = oracle_mod.Framebuffer(W, H)
+    for p in range(pass0, pass0 + npass):
+        s.render_range(fb, 0, W * H - 1, depth, bool(preview), p, ns, seed)
+    accum, argb = fb.read()
+    assert (argb == g["argb"]).all()
+    if not preview:         # a preview pass writes the picture only
+        assert (bits(accum) == bits(g["accum"])).all()
