@@ -107,6 +107,15 @@ int rtw_scene_destroy(rtw_scene* scene);
 /* RayTracerScene::AddShape(RMeshShape::Create(path), ...) : OBJ + sibling MTL + PNG
  * textures with the reference's parser semantics (Src/MeshShape.cpp:65-278). */
 int rtw_scene_add_mesh_obj(rtw_scene* scene, const char* obj_path, int* out_shape);
+/* RayTracerScene::AddShape(RSphere::Create(center, radius), ...) / RPlane::Create(normal, point) / RCapsule::Create(start, end,
+ * radius) (Src/Shapes.h:46-112; intersections Src/RRay.cpp:25-87 and Src/Shapes.cpp:18-125).  Shapes keep their insertion order
+ * (it decides which of two hits at one distance wins, and which hit's sampled colour a later sphere / plane / capsule-side hit
+ * inherits: one RayHitResult serves all shapes of a query, Src/RayTracerScene.cpp:99-125).  A plane has no culling box
+ * (RPlane::HasCullingBounds).  The material is set with rtw_scene_set_material as for a mesh.  Scenes with such shapes render
+ * through the bins + wave pipeline or, when a textured mesh precedes one of them, through the single kernel (pipeline 0). */
+int rtw_scene_add_sphere(rtw_scene* scene, const float center[3], float radius, int* out_shape);
+int rtw_scene_add_plane(rtw_scene* scene, const float normal[3], const float point[3], int* out_shape);
+int rtw_scene_add_capsule(rtw_scene* scene, const float start[3], const float end[3], float radius, int* out_shape);
 /* Same, from arrays the caller already holds (the members of RMeshShape,
  * Src/MeshShape.h:25-37).  positions/texcoords/normals are 3 floats per element,
  * idx_* are 3 ints per triangle (0-based), tri_material is 1 int per triangle (-1 = none).

@@ -196,6 +196,39 @@ class RMeshShape:
                                       nidx=nidx, matid=matid, bounds=bounds, textures=textures or {}))
 
 
+class RSphere:
+    """RSphere::Create(center, radius) (Src/Shapes.h:46-60)"""
+
+    def __init__(self, Center, Radius):
+        self.Center, self.Radius = tuple(float(v) for v in Center), float(Radius)
+
+    @staticmethod
+    def Create(InCenter, InRadius):
+        return RSphere(InCenter, InRadius)
+
+
+class RPlane:
+    """RPlane::Create(normal, point) (Src/Shapes.h:63-79): infinite, never culled"""
+
+    def __init__(self, Normal, Point):
+        self.Normal, self.Point = tuple(float(v) for v in Normal), tuple(float(v) for v in Point)
+
+    @staticmethod
+    def Create(InNormal, InPoint):
+        return RPlane(InNormal, InPoint)
+
+
+class RCapsule:
+    """RCapsule::Create(start, end, radius) (Src/Shapes.h:82-104)"""
+
+    def __init__(self, Start, End, Radius):
+        self.Start, self.End, self.Radius = tuple(float(v) for v in Start), tuple(float(v) for v in End), float(Radius)
+
+    @staticmethod
+    def Create(InStart, InEnd, InRadius):
+        return RCapsule(InStart, InEnd, InRadius)
+
+
 # ---------------------------------------------------------------------------------------------
 _live_contexts = weakref.WeakSet()
 
@@ -316,7 +349,14 @@ class RayTracerScene:
     def AddShape(self, Shape, SurfaceMaterial=None):
         L = library()
         idx = C.c_int(-1)
-        if Shape.Filename is not None:
+        v3 = lambda v: (C.c_float * 3)(*v)  # noqa: E731
+        if isinstance(Shape, RSphere):
+            _check(L.rtw_scene_add_sphere(self.h, v3(Shape.Center), C.c_float(Shape.Radius), C.byref(idx)))
+        elif isinstance(Shape, RPlane):
+            _check(L.rtw_scene_add_plane(self.h, v3(Shape.Normal), v3(Shape.Point), C.byref(idx)))
+        elif isinstance(Shape, RCapsule):
+            _check(L.rtw_scene_add_capsule(self.h, v3(Shape.Start), v3(Shape.End), C.c_float(Shape.Radius), C.byref(idx)))
+        elif Shape.Filename is not None:
             _check(L.rtw_scene_add_mesh_obj(self.h, Shape.Filename.encode(), C.byref(idx)))
         else:
             a = Shape.arrays

@@ -733,6 +733,88 @@ __device__ __forceinline__ void texture_sample(const uint32_t* __restrict__ texe
     alpha = lerpf(lerpf(a00, a01, dx), lerpf(a10, a11, dx), dy);
 }
 
+// ---- RSphere / RPlane / RCapsule (Src/Shapes.cpp:18-125) ---------------------------------------------------------------
+// `seg` is TestRay.Distance at the time of the test (FindIntersectionWithScene shortens it hit by hit).
+// RRay::TestIntersectionWithSphere (Src/RRay.cpp:25-66): quadratic in the parameter of Origin + t * (Direction * Distance)
+__device__ __forceinline__ bool sphere_test(const Ray& r, float seg, f3 c, float radius, f3& pos, float& dist)
+{
+    const float dx = r.d.x * seg, dy = r.d.y * seg, dz = r.d.z * seg;
+    const f3 o = r.o;
+    const float qa = dx * dx + dy * dy + dz * dz;
+    const float qb = 2.0f * dx * (o.x - c.x) + 2.0f * dy * (o.y - c.y) + 2.0f * dz * (o.z - c.z);
+    const float qc = c.x * c.x + c.y * c.y + c.z * c.z + o.x * o.x + o.y * o.y + o.z * o.z +
+                     -2.0f * (c.x * o.x + c.y * o.y + c.z * o.z) - radius * radius;
+    const float d = qb * qb - 4.0f * qa * qc;
+    if (!(d >= 0.0f)) return false;
+    const float t = (-qb - sqrtf(d)) / (qa * 2.0f);
+    if (t <= 0.0f) return false;
+    const f3 hp = mk(o.x + t * dx, o.y + t * dy, o.z + t * dz);
+    const f3 rel = hp - o;
+    const float len = sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z);
+    if (len > seg) return false;
+    pos = hp; dist = len;
+    return true;
+}
+// RRay::TestIntersectionWithPlane (Src/RRay.cpp:68-87); its `fabsf(denom) > 1e-6` compares in double
+__device__ __forceinline__ bool plane_test(const Ray& r, float seg, f3 n, f3 pt, f3& pos, float& dist)
+{
+    const float denom = dot(n, r.d);
+    if (!((double)fabsf(denom) > 1e-6)) return false;
+    const float t = dot(pt - r.o, n) / denom;
+    if (!(t >= 0.0f && t < seg)) return false;
+    pos = r.o + r.d * t; dist = t;
+    return true;
+}
+// RCapsule::TestRayCylinderIntersection (Src/Shapes.cpp:64-125)
+__device__ __forceinline__ bool cylinder_test(const Ray& r, f3 start, f3 end, float radius, f3& pos, float& dist)
+{
+    const f3 d = end - start, m = r.o - start;
+    const float dd = dot(d, d), nd = dot(r.d, d), mn = dot(m, r.d), md = dot(m, d), mm = dot(m, m);
+    if (dot(r.o - start, end - start) < 0.0f && dot(r.d, end - start) < 0.0f) return false;
+    if (dot(r.o - end, start - end) < 0.0f && dot(r.d, start - end) < 0.0f) return false;
+    const float a = dd - nd * nd;
+    const float b = dd * mn - nd * md;
+    const float c = dd * (mm - radius * radius) - md * md;
+    if (fabsf(a) < FLT_EPSILON) return false;
+    if ((b * b - a * c) < 0.0f) return false;
+    const float rt = (-b - sqrtf(b * b - a * c)) / a;
+    if (rt < 0.0f) return false;
+    const f3 v = r.o + r.d * rt;
+    if (dot(v - start, end - start) < 0.0f) return false;
+    if (dot(v - end, start - end) < 0.0f) return false;
+    pos = v; dist = rt;
+    return true;
+}
+// One analytic shape against the ray.  `part` tells what wrote the result: 0 = a sphere, a plane or a capsule's side (they set
+// position, normal and distance only: the result's sampled colour and alpha stay what an earlier shape left there), 1 / 2 = the
+// capsule's end sphere at Start / End (RCapsule::TestRayIntersection copies a fresh RayHitResult in, which resets them;
+// of two end hits the nearer, the second on a tie: Src/Shapes.cpp:34-62).
+__device__ __forceinline__ bool analytic_test(const RtwShapeDev& sh, const Ray& r, float seg, f3& pos, float& dist, int& part)
+{
+    const f3 a = mk(sh.pa[0], sh.pa[1], sh.pa[2]), b = mk(sh.pb[0], sh.pb[1], sh.pb[2]);
+    part = 0;
+    if (sh.kind == RTW_SHAPE_SPHERE) return sphere_test(r, seg, a, sh.radius, pos, dist);
+    if (sh.kind == RTW_SHAPE_PLANE) return plane_test(r, seg, a, b, pos, dist);
+    if (sh.kind != RTW_SHAPE_CAPSULE) return false;
+    if (cylinder_test(r, a, b, sh.radius, pos, dist)) return true;
+    f3 p1 = mk(0, 0, 0), p2 = mk(0, 0, 0); float d1 = 0.0f, d2 = 0.0f;
+    const bool b1 = sphere_test(r, seg, a, sh.radius, p1, d1);
+    const bool b2 = sphere_test(r, seg, b, sh.radius, p2, d2);
+    if (b1 && (!b2 || d1 < d2)) { pos = p1; dist = d1; part = 1; return true; }
+    if (b2) { pos = p2; dist = d2; part = 2; return true; }
+    return false;
+}
+// the normal that test wrote, from the hit position it wrote (the same operations on the same values)
+__device__ __forceinline__ f3 analytic_normal(const RtwShapeDev& sh, f3 pos, int part)
+{
+    const f3 a = mk(sh.pa[0], sh.pa[1], sh.pa[2]), b = mk(sh.pb[0], sh.pb[1], sh.pb[2]);
+    if (sh.kind == RTW_SHAPE_PLANE) return a;
+    if (sh.kind == RTW_SHAPE_SPHERE || part == 1) return normalized(pos - a);
+    if (part == 2) return normalized(pos - b);
+    const f3 side = cross(b - a, pos - a);
+    return normalized(cross(side, b - a));
+}
+
 // ---- RMeshShape::TestRayIntersection (Src/MeshShape.cpp:280-332) ------------------------------------
 // The part of RMeshShape::TestRayIntersection after the tree query (Src/MeshShape.cpp:288-327): barycentrics,
 // fast-normalised smooth normal, texture sample.
@@ -769,6 +851,17 @@ __device__ __forceinline__ void mesh_finish(const RtwSceneDev* __restrict__ sc, 
     }
 }
 
+// A recorded hit (shape, position, distance, leaf slot or analytic part) -> the RayHitResult RayTrace shades.  Records are only
+// kept for scenes in which no analytic hit can inherit a texel (the host sends the others through the single kernel).
+template <bool STATS>
+__device__ __forceinline__ void hit_finish(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, const TravCtx& tc,
+                                           f3 pos, float cur, int slot, Hit& out, int& tri_index, Counters& ct)
+{
+    if (sh.kind == RTW_SHAPE_MESH) { mesh_finish<STATS>(sc, sh, tc, pos, cur, slot, out, tri_index, ct); return; }
+    out.pos = pos; out.dist = cur; out.normal = analytic_normal(sh, pos, slot);
+    out.color = mk(1.0f, 1.0f, 1.0f); out.alpha = 1.0f;
+    tri_index = -1;
+}
 
 // LPR = lanes per ray (1, or 4 in the quartet path kernel); LDSQ = shape 0's quads are staged in LDS.
 // In a quartet the four lanes run everything but quad_walk4 redundantly on identical state; Counters
@@ -822,11 +915,24 @@ __device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__
     int hit_shape = -1;
     float seg = in.dist;
     if (STATS && tc.count) ct.rays++;
+    out.color = mk(1.0f, 1.0f, 1.0f); out.alpha = 1.0f;      // RayHitResult() (Src/RRay.h:15-20); ONE result serves every shape below
     for (int s = 0; s < sc->n_shapes; s++) {
         const RtwShapeDev& sh = sc->shapes[s];
-        float t0, t1;
-        if (STATS && tc.count) ct.boxes++;
-        if (!slab_exact(in, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+        if (sh.kind != RTW_SHAPE_PLANE) {                    // RPlane::HasCullingBounds() is false (Src/Shapes.cpp:28-32)
+            float t0, t1;
+            if (STATS && tc.count) ct.boxes++;
+            if (!slab_exact(in, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+        }
+        if (sh.kind != RTW_SHAPE_MESH) {
+            f3 pos; float dist; int part;
+            if (analytic_test(sh, in, seg, pos, dist, part)) {
+                out.pos = pos; out.dist = dist; out.normal = analytic_normal(sh, pos, part);
+                if (part != 0) { out.color = mk(1.0f, 1.0f, 1.0f); out.alpha = 1.0f; }
+                tri_index = -1;
+                seg = dist; hit_shape = s;
+            }
+            continue;
+        }
         if (mesh_query<STATS, LPR, LDSQ>(sc, sh, s == 0, tc, in, seg, out, tri_index, ct)) { seg = out.dist; hit_shape = s; }
     }
     return hit_shape;
@@ -1500,7 +1606,7 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
         else {
             const RtwShapeDev& sh = sc->shapes[hs];
             Hit h; int tri_index;
-            mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+            hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
             if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
             else {
                 Ray out = ray;

@@ -26,6 +26,8 @@ struct HostMesh {
     std::vector<HostTexture> textures;                          // per material id
     int n_textures_slots = 0;          // size of the reference's Textures vector (0 without an MTL)
     float bmin[3], bmax[3];            // RShape::Aabb
+    int kind = RTW_SHAPE_MESH;         // a sphere / plane / capsule is a shape record without arrays (Src/Shapes.h:46-112)
+    float pa[3] = { 0, 0, 0 }, pb[3] = { 0, 0, 0 }, radius = 0;
     std::vector<RtwMaterialNode> material;
     // built by build_tree():
     std::vector<RtwNode> nodes;

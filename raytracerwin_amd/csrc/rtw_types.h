@@ -68,6 +68,10 @@ struct RtwMaterialNode {    // mirrors rtw_material_node
 #define RTW_DEV_MAX_TEXTURES 64
 #define RTW_DEV_MAX_MATERIAL_NODES 64
 #define RTW_DEV_MAX_SHAPES 8
+#define RTW_SHAPE_MESH 0
+#define RTW_SHAPE_SPHERE 1
+#define RTW_SHAPE_PLANE 2
+#define RTW_SHAPE_CAPSULE 3
 
 struct RtwShapeDev {
     const RtwNode* nodes;
@@ -90,7 +94,11 @@ struct RtwShapeDev {
     int32_t n_textures;             // size of the reference's Textures vector (= triangle count when an MTL exists)
     int32_t has_material;
     int32_t n_material_nodes;
-    int32_t pad;
+    // RTW_SHAPE_MESH: everything above; a sphere / plane / capsule has no arrays, only these (Src/Shapes.h:46-112):
+    //   sphere: pa = Center, radius;  plane: pa = Normal, pb = Point;  capsule: pa = Start, pb = End, radius
+    int32_t kind;
+    float pa[3], pb[3], radius;
+    int32_t pad_kind;
     RtwTexture textures[RTW_DEV_MAX_TEXTURES];
     RtwMaterialNode material[RTW_DEV_MAX_MATERIAL_NODES];
 };

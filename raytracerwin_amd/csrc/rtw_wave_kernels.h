@@ -214,6 +214,12 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
     fr.eps_t = 2.0e-5f * fmaxf(fabsf(fr.ix), fmaxf(fabsf(fr.iy), fabsf(fr.iz)));
     for (int s = 0; s < n_shapes; s++) {
         const FlatSrc g = (s == 0) ? shape0 : flat_src_of(sc->shapes[s]);
+        const int kind = sc->shapes[s].kind;
+        if (kind == RTW_SHAPE_PLANE) {      // no culling box (RPlane::HasCullingBounds); every lane computes the one ray's test alike
+            f3 pos; float dist; int part;
+            if (analytic_test(sc->shapes[s], ray, seg, pos, dist, part)) { seg = dist; hit_shape = s; hit_slot = part; hit_pos = pos; }
+            continue;
+        }
         if (STATS && one) ct.boxes++;
         bool in_bound;
         if (tame) {         // RRay::TestIntersectionWithAabb with no axis skipped and no NaN: same operations, reciprocals reused
@@ -230,7 +236,9 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
         if (!in_bound) continue;
         float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
         bool any;
-        if (g.n[0] > 0) {
+        if (kind != RTW_SHAPE_MESH) {       // a sphere or a capsule: the record's slot says which part was hit
+            any = analytic_test(sc->shapes[s], ray, seg, pos, cur, slot);
+        } else if (g.n[0] > 0) {
             if (tame) {
                 if (STAGE > 0 && s == 0) any = wave_walk_flat<STATS, STAGE, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
                 else any = wave_walk_flat<STATS, 0, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     bool near_wave = false;
     for (int k = 0; k < n_shapes; k++) {
         const uint32_t* __restrict__ boff = p.bins[k].off;
-        near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);
+        near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);     // (a sphere / plane / capsule has no bins)
     }
     f3 csum = mk(0, 0, 0);                                   // s[0] + s[1] + ... in sample order, as the reference adds them
     uint32_t queued = 0u;
@@ -363,14 +371,18 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
             const bool skx = near_zero(ray.d.x), sky = near_zero(ray.d.y), skz = near_zero(ray.d.z);
             for (int k = 0; k < n_shapes; k++) {
                 const RtwShapeDev& sh = sc->shapes[k];
+                const int kind = sh.kind;
                 float t0, t1;
-                const bool inbox = live && slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1);
-                if (STATS && live) ct.boxes++;
+                const bool inbox = live && (kind == RTW_SHAPE_PLANE ||      // a plane has no culling box (RPlane::HasCullingBounds)
+                                            slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1));
+                if (STATS && live && kind != RTW_SHAPE_PLANE) ct.boxes++;
                 if (__ballot(inbox) == 0ull) continue;
                 float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
                 bool any = false;
                 const uint32_t* __restrict__ boff = p.bins[k].off;
-                if (boff == nullptr) {                       // no bins for this shape: packet walk of its tree
+                if (kind != RTW_SHAPE_MESH) {                // a sphere / plane / capsule: every lane tests its own ray; slot = the part hit
+                    if (inbox) any = analytic_test(sh, ray, seg, pos, cur, slot);
+                } else if (boff == nullptr) {                // no bins for this shape: packet walk of its tree
                     any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
                     if (any_untame) {
                         const bool a2 = packet_walk<STATS, true>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && !tame, false, cur, pos, slot, ct);
@@ -618,7 +630,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
                     else {
                         const RtwShapeDev& sh = sc->shapes[hs];
                         Hit h; int tri_index;
-                        mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+                        hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
                         if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
                         else {
                             Ray out = ray;

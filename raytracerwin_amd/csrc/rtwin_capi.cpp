@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <cfloat>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -116,6 +117,9 @@ struct rtw_scene {
     rtw_context* ctx = nullptr;
     std::vector<std::unique_ptr<rtw::HostMesh>> meshes;
     bool committed = false;
+    bool has_analytic = false;          // some shape is a sphere / plane / capsule
+    bool texture_carry = false;         // ... and comes after a textured mesh: its hits can inherit that mesh's sampled colour
+                                        // (one RayHitResult serves all shapes, Src/RayTracerScene.cpp:99-125) -> single-kernel pipeline
     int prune = 1;
     int traversal = 1;
     RtwSceneDev* d_scene = nullptr;
@@ -382,6 +386,42 @@ int rtw_scene_add_mesh(rtw_scene* scene, const float* positions, int n_positions
     return RTW_OK;
 }
 
+// RSphere / RPlane / RCapsule (Src/Shapes.h:46-112): a shape record without arrays.  The culling box is RAabb::ExpandBySphere
+// (Src/RAabb.h:46-54) from the default box (Src/RAabb.cpp:13-17), in the reference's float operations.
+static void expand_by_sphere(rtw::HostMesh& m, const float c[3], float r)
+{
+    for (int k = 0; k < 3; k++) {
+        if (c[k] - r < m.bmin[k]) m.bmin[k] = c[k] - r;
+        if (c[k] + r > m.bmax[k]) m.bmax[k] = c[k] + r;
+    }
+}
+static int add_analytic(rtw_scene* scene, int kind, const float* a, const float* b, float radius, int* out_shape)
+{
+    if (!scene || !a || (kind != RTW_SHAPE_SPHERE && !b)) return fail(RTW_ERR_INVALID, "null argument");
+    if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
+    if ((int)scene->meshes.size() >= RTW_DEV_MAX_SHAPES) return fail(RTW_ERR_LIMIT, "too many shapes");
+    std::unique_ptr<rtw::HostMesh> m(new rtw::HostMesh());
+    m->kind = kind; m->radius = radius;
+    for (int k = 0; k < 3; k++) { m->pa[k] = a[k]; m->pb[k] = b ? b[k] : 0.0f; m->bmin[k] = FLT_MAX; m->bmax[k] = -FLT_MAX; }
+    if (kind == RTW_SHAPE_SPHERE) expand_by_sphere(*m, m->pa, radius);
+    if (kind == RTW_SHAPE_CAPSULE) { expand_by_sphere(*m, m->pa, radius); expand_by_sphere(*m, m->pb, radius); }
+    scene->meshes.push_back(std::move(m));
+    if (out_shape) *out_shape = (int)scene->meshes.size() - 1;
+    return RTW_OK;
+}
+int rtw_scene_add_sphere(rtw_scene* scene, const float center[3], float radius, int* out_shape)
+{
+    return add_analytic(scene, RTW_SHAPE_SPHERE, center, nullptr, radius, out_shape);
+}
+int rtw_scene_add_plane(rtw_scene* scene, const float normal[3], const float point[3], int* out_shape)
+{
+    return add_analytic(scene, RTW_SHAPE_PLANE, normal, point, 0.0f, out_shape);
+}
+int rtw_scene_add_capsule(rtw_scene* scene, const float start[3], const float end[3], float radius, int* out_shape)
+{
+    return add_analytic(scene, RTW_SHAPE_CAPSULE, start, end, radius, out_shape);
+}
+
 int rtw_scene_set_texture(rtw_scene* scene, int shape, int material_id, const uint8_t* texels, int width, int height, int channels)
 {
     if (!scene || !texels) return fail(RTW_ERR_INVALID, "null argument");
@@ -474,6 +514,7 @@ int rtw_scene_commit(rtw_scene* scene)
     h->gamma_thr = scene->ctx->d_gamma;
     h->texel_lut = scene->ctx->d_lut;
     h->stats = scene->ctx->d_stats;
+    bool textured_mesh_before = false;
     for (size_t s = 0; s < scene->meshes.size(); s++) {
         rtw::HostMesh& m = *scene->meshes[s];
         rtw::build_tree(m);
@@ -511,6 +552,14 @@ int rtw_scene_commit(rtw_scene* scene)
         d.has_material = m.material.empty() ? 0 : 1;
         d.n_material_nodes = (int)m.material.size();
         for (size_t k = 0; k < m.material.size(); k++) d.material[k] = m.material[k];
+        d.kind = m.kind; d.radius = m.radius;
+        for (int k = 0; k < 3; k++) { d.pa[k] = m.pa[k]; d.pb[k] = m.pb[k]; }
+        if (m.kind != RTW_SHAPE_MESH) {
+            scene->has_analytic = true;
+            if (textured_mesh_before) scene->texture_carry = true;
+        } else {
+            for (const rtw::HostTexture& tx : m.textures) if (tx.valid) textured_mesh_before = true;
+        }
     }
     void* dsc = nullptr;
     HIP_TRY(hipMalloc(&dsc, sizeof(RtwSceneDev)));
@@ -759,6 +808,7 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
     for (size_t s = 0; s < scene->meshes.size(); s++) {
         std::vector<uint32_t> off, ent;
         h[s].off = nullptr; h[s].ent = nullptr;
+        if (scene->meshes[s]->kind != RTW_SHAPE_MESH) { for (auto& w : weight) w += 1u; continue; }      // tested by every sample of every tile
         if (!rtw::build_bins(*scene->meshes[s], width, height, bin_w, bin_h, off, ent)) { for (auto& w : weight) w += 1000u; continue; }
         for (size_t b = 0; b < n_bins; b++) weight[b] += off[b + 1] - off[b];
         int rc;
@@ -871,6 +921,11 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     hipError_t e;
     // the bins + wave pipeline needs whole rows, the flat hierarchy (traversal != 0) and a frame that tiles; else pipeline 2
     int pipeline = scene->ctx->pipeline;
+    // spheres / planes / capsules are built into the bins + wave pipeline and the single kernel; the two older pipelines
+    // (options 1 and 2) then run as the single kernel, and so does a scene whose analytic hits can inherit a texel
+    const int fallback = scene->has_analytic ? 0 : 2;
+    if (scene->has_analytic && (pipeline == 1 || pipeline == 2)) pipeline = 0;
+    if (scene->texture_carry) pipeline = 0;
     int sky_job0 = 0;
     if (pipeline == 3) {
         RtwRenderParams tiled = p;
@@ -885,7 +940,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
             sky_job0 = jt ? jt->n_busy : 0;
             if (used_bins_pipeline) *used_bins_pipeline = true;
         } else {
-            pipeline = 2;
+            pipeline = fallback;
         }
     }
     if (pipeline >= 1) {

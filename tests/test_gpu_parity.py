@@ -421,3 +421,94 @@ def test_randomised_scenes_frames_and_options_bins_equal_single_kernel(ctx):
     lines = []
     bad = mod.run(20261004, 60, ctx, lambda *a, **k: lines.append(" ".join(str(x) for x in a)))
     assert bad == 0, [ln for ln in lines if ln.endswith("DIFF")]
+
+
+# ---- multi-shape scenes: RSphere / RPlane / RCapsule beside meshes (tests/scenes.py) ----------------------------------
+import scenes as SC  # noqa: E402
+from oracle import oracle as _O  # noqa: E402  (material node arrays only)
+
+
+def multi_scene_gpu(ctx, tag):
+    s = R.RayTracerScene(ctx)
+    for sh in SC.SCENES[tag]():
+        mat = None if sh[-1] is None else R.material_nodes_from_array(_O.materials(sh[-1]))
+        if sh[0] == "sphere":
+            s.AddShape(R.RSphere.Create(sh[1], sh[2]), mat)
+        elif sh[0] == "plane":
+            s.AddShape(R.RPlane.Create(sh[1], sh[2]), mat)
+        elif sh[0] == "capsule":
+            s.AddShape(R.RCapsule.Create(sh[1], sh[2], sh[3]), mat)
+        else:
+            s.AddShape(R.RMeshShape.Create(asset(sh[1] + ".obj")), mat)
+    s.commit()
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["default_nofuzz", "quirk", "shapes"])
+def test_scene_closest_hit_vs_reference_golden(ctx, tag):
+    """FindIntersectionWithScene over spheres, planes, capsules and meshes in insertion order, bit-exact against the reference's
+    own outputs -- including (scene "quirk") the sampled colour an analytic hit inherits from an earlier textured-mesh hit."""
+    g = np.load(os.path.join(GOLDEN, "sceneclosest_%s.npz" % tag))
+    s = multi_scene_gpu(ctx, tag)
+    hit, shape, tri = s.FindIntersectionWithScene(g["rays"])
+    assert (shape == g["shape"]).all()
+    m = shape >= 0
+    assert same(hit[m], g["hit"][m])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default_nofuzz_d5", "default_preview", "quirk_d4", "quirk_preview", "shapes_d6", "shapes_1spp_d2"])
+@pytest.mark.parametrize("pipeline", [3, 0])
+def test_scene_frame_vs_reference_golden(ctx, name, pipeline):
+    """RayTracerProgram::SetupScene's scene (fuzziness zeroed, see tests/scenes.py), the texture-inheritance scene and the
+    analytic-only scene: the frames the reference's RayTrace rendered, bit for bit, through the default pipeline and the single kernel."""
+    g = np.load(os.path.join(GOLDEN, "sceneframe_%s.npz" % name))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    s = multi_scene_gpu(ctx, str(g["scene"]))
+    ctx.set_option("pipeline", pipeline)
+    try:
+        accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
+    finally:
+        ctx.set_option("pipeline", 3)
+    assert (argb == g["argb"]).all()
+    if not preview:
+        assert (bits(accum) == bits(g["accum"])).all()
+
+
+@pytest.mark.gpu
+def test_default_scene_with_fuzz_vs_oracle_f64_mode_and_close_to_reference(ctx, oracle_mod):
+    """SetupScene as written (fuzzy reflections on the capsule, the ground and the mesh): bit-exact against the oracle in the
+    device's transcendental mode, and within 1e-4 of the reference's frame on >= 99 % of the pixels."""
+    O = oracle_mod
+    g = np.load(os.path.join(GOLDEN, "sceneframe_default_d5.npz"))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    os_ = O.Scene().add_shapes(SC.SCENES["default"](), lambda n: asset(n + ".obj"))
+    os_.set_unitvec_mode(O.UNITVEC_F64)
+    ofb = O.Framebuffer(W, H)
+    for p in range(pass0, pass0 + npass):
+        os_.render_range(ofb, 0, W * H - 1, depth, False, p, ns, seed)
+    oa, ob = ofb.read()
+    s = multi_scene_gpu(ctx, "default")
+    accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
+    assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
+    d = np.abs(accum[:, :3] - g["accum"][:, :3]).max(axis=1)
+    assert (d <= 1e-4).mean() >= 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,W,H,ns,depth", [("default", 1280, 720, 4, 5), ("shapes", 800, 800, 4, 6), ("default_nofuzz", 333, 211, 3, 4),
+                                              ("quirk", 640, 360, 4, 4)])
+def test_scene_pipelines_agree_at_size(ctx, tag, W, H, ns, depth):
+    """larger frames than the oracle-sized fixtures: bins + wave pipeline == single kernel, whole frame and dealt as tasks over 3 ranks"""
+    s = multi_scene_gpu(ctx, tag)
+    ctx.set_option("pipeline", 0)
+    a0, b0 = render_frame(ctx, s, W, H, ns, depth, 0, 31, 0, 2)
+    ctx.set_option("pipeline", 3)
+    a3, b3 = render_frame(ctx, s, W, H, ns, depth, 0, 31, 0, 2)
+    assert (bits(a0) == bits(a3)).all() and (b0 == b3).all()
+    fb = R.Framebuffer(ctx, W, H)
+    for p in range(2):
+        for rank in range(3):
+            s.render_tasks(fb, 10, rank, 3, depth, None, p, ns, 31)
+    assert (bits(fb.read_float()) == bits(a3)).all()

@@ -263,3 +263,26 @@ def test_meshes_reaching_behind_the_camera_get_no_bins(tmp_path):
     s.AddShape(R.RMeshShape.Create(str(p)))
     assert s.mesh_bins(192, 108, 16, 4) is None
     assert s.mesh_bins(100, 108, 16, 4) is None        # a frame the bins do not tile
+
+
+def test_analytic_shapes_keep_insertion_order_and_the_reference_culling_boxes(oracle_mod):
+    """RSphere / RCapsule boxes are RAabb::ExpandBySphere from the default box (Src/RAabb.h:46-54, Src/Shapes.h:52,91-92); a plane's
+    stays the default inverted box (never consulted: RPlane::HasCullingBounds).  Host-only scene, compared with the oracle's."""
+    import scenes as SC
+    s = R.RayTracerScene(None)
+    o = oracle_mod.Scene()
+    shapes = [("sphere", (1.5, 2.5, -2.0), 0.9, None), ("plane", (0.0, 1.0, 0.0), (0.0, -2.0, 0.0), None),
+              ("capsule", (-1.5, -1.5, -1.5), (-2.0, -1.5, 0.0), 0.5, None), ("sphere", (0.1, 0.2, 0.3), 1e-3, None)]
+    o.add_shapes(shapes, None)
+    assert s.AddShape(R.RSphere.Create(shapes[0][1], shapes[0][2])) == 0
+    assert s.AddShape(R.RPlane.Create(shapes[1][1], shapes[1][2])) == 1
+    assert s.AddShape(R.RCapsule.Create(shapes[2][1], shapes[2][2], shapes[2][3]), R.SurfaceMaterial_Diffuse()) == 2
+    assert s.AddShape(R.RSphere.Create(shapes[3][1], shapes[3][2])) == 3
+    s.commit()
+    for k in range(4):
+        info = s.mesh_info(k)
+        assert info["tris"] == 0 and info["nodes"] == 0
+        assert (info["bounds"].view(np.uint32) == o.shape_bounds(k).view(np.uint32)).all(), k
+    assert len(SC.default_scene()) == 7
+    with pytest.raises(R.RtwError):
+        s.AddShape(R.RSphere.Create((0, 0, 0), 1.0))        # committed

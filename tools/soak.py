@@ -3,8 +3,8 @@
 
   python tools/soak.py [--seed S] [--cases N]
 
-Every case draws a scene (one of the three OBJ assets, two of them together, or a random triangle soup with degenerate,
-axis-aligned, coincident and behind-the-camera triangles), a material tree, a frame shape (including tall / narrow / odd sizes),
+Every case draws a scene (one of the three OBJ assets, two of them together, random spheres / planes / capsules alone or around a
+mesh, or a random triangle soup with degenerate, axis-aligned, coincident and behind-the-camera triangles), a material tree, a frame shape (including tall / narrow / odd sizes),
 spp, depth, preview flag, passes, a rank split and random pipeline options, renders it through the one-thread-per-pixel kernel
 (pipeline 0, the most literal reading of ThreadWorker_Render, Src/RayTracerProgram.cpp:130-189) and through the default bins + wave
 pipeline, and compares accumulator and ARGB bits.  Prints one line per case and the number of mismatches; exit code 1 on any."""
@@ -38,6 +38,18 @@ def soup(rng, kind):
     return R.RMeshShape.FromArrays(pts, tcs, nrm, idx, idx, idx)
 
 
+def analytic(rng):
+    k = int(rng.integers(0, 3))
+    v = lambda lo, hi: tuple(float(x) for x in rng.uniform(lo, hi, 3))  # noqa: E731
+    if k == 0:
+        return R.RSphere.Create(v(-3, 3), float(rng.choice([0.05, 0.5, 1.5, 8.0])))       # 8.0: the camera may sit inside
+    if k == 1:
+        n = np.asarray(v(-1, 1)); n /= max(np.linalg.norm(n), 1e-6)
+        return R.RPlane.Create(tuple(float(x) for x in (n if rng.random() < 0.7 else n * 3)), v(-3, 3))
+    a = v(-3, 3)
+    return R.RCapsule.Create(a, a if rng.random() < 0.1 else v(-3, 3), float(rng.choice([0.1, 0.4, 1.0])))
+
+
 def material(rng, depth=0):
     k = int(rng.integers(0, 7 if depth < 2 else 4))
     col = tuple(float(v) for v in rng.uniform(0.2, 1.0, 3))
@@ -62,9 +74,18 @@ def run(seed_arg, cases, ctx=None, log=print):
     objs = ("TorusKnot", "BlenderMonkey", "unitychan")
     bad = 0
     for it in range(cases):
-        kind = str(rng.choice(["obj", "obj", "obj", "two", "soup", "flat", "degenerate", "behind"]))
+        kind = str(rng.choice(["obj", "obj", "obj", "two", "soup", "flat", "degenerate", "behind", "shapes", "shapes", "mixed", "mixed"]))
         s = R.RayTracerScene(ctx)
-        if kind in ("obj", "two"):
+        if kind in ("shapes", "mixed"):       # spheres / planes / capsules, alone or around a mesh (before it: no texel is inherited;
+            order = ["a"] * int(rng.integers(1, 6))     # after a textured one: the library takes the single kernel for both runs)
+            if kind == "mixed":
+                order.insert(int(rng.integers(0, len(order) + 1)), "m")
+            for o in order:
+                if o == "a":
+                    s.AddShape(analytic(rng), material(rng) if rng.random() < 0.9 else None)
+                else:
+                    s.AddShape(R.RMeshShape.Create(os.path.join(ROOT, "assets", "%s.obj" % rng.choice(objs))), material(rng))
+        elif kind in ("obj", "two"):
             for m in rng.choice(objs, 2 if kind == "two" else 1, replace=False):
                 s.AddShape(R.RMeshShape.Create(os.path.join(ROOT, "assets", "%s.obj" % m)), material(rng) if rng.random() < 0.8 else None)
         else:
