@@ -34,6 +34,8 @@ CONFIGS = {
     "c2": ("TorusKnot", 1920, 1080, 1, 4, "diffuse"),
     "c3": ("BlenderMonkey", 1920, 1080, 4, 6, "blend"),
     "c4": ("unitychan", 1920, 1080, 4, 4, "diffuse"),
+    # RayTracerProgram::SetupScene (4 spheres, capsule, ground plane, unitychan) at the reference's window size and bounce limit
+    "setup": ("unitychan", 800, 800, 4, 10, "setup"),
 }
 SEED = 12345
 TASK_ROWS = 10          # NumTaskRows, Src/RayTracerProgram.cpp:282
@@ -85,9 +87,70 @@ def algorithmic_bytes(st, pixels):
     return 32 * st["box_tests"] + 64 * st["tri_tests"] + 140 * st["shaded_hits"] + 16 * st["tex_samples"] + 36 * pixels
 
 
+def oracle_nodes(O, m):
+    """nested material tuple of raytracerwin_amd.setup_scene -> the oracle's preorder node list"""
+    k = m[0]
+    if k == "diffuse":
+        return [(O.MAT_DIFFUSE, m[1], 0, 0, 0)]
+    if k == "checker":
+        return [(O.MAT_DIFFUSE_CHECKER, m[1], m[2], 0, 0)]
+    if k == "reflective":
+        return [(O.MAT_REFLECTIVE, m[1], m[2], 0, 0)]
+    if k == "emissive":
+        return [(O.MAT_EMISSIVE, m[1], 0, 0, 0)]
+    a, b = oracle_nodes(O, m[1]), oracle_nodes(O, m[2])
+    pair = (O.MAT_BLEND, O.MAT_COMBINE)
+    shift = lambda nodes, off: [(t, c, q, x + off if t in pair else x, y + off if t in pair else y) for t, c, q, x, y in nodes]  # noqa: E731
+    return [(O.MAT_BLEND if k == "blend" else O.MAT_COMBINE, (0, 0, 0), m[3] if k == "blend" else 0, 1, 1 + len(a))] + shift(a, 1) + shift(b, 1 + len(a))
+
+
+def cpu_baseline_setup(mesh_path, W, H, spp, depth, rays_per_frame, budget_s):
+    """SetupScene on the host cores: the reference's own translation units when oracle/_ref is there (the scene handed to the
+    harness as a .scene file), else the oracle port."""
+    from oracle import oracle as O
+    from raytracerwin_amd.setup_scene import SHAPES
+    cores = O.hw_threads()
+    num = lambda v: " ".join("%.17g" % float(np.float32(x)) for x in (v if isinstance(v, (tuple, list)) else [v]))  # noqa: E731
+    if os.path.exists(O.REF_HARNESS):
+        with tempfile.TemporaryDirectory() as tmp:
+            lines = []
+            for k, sh in enumerate(SHAPES):
+                mp = os.path.join(tmp, "mat%d.bin" % k)
+                O.materials(oracle_nodes(O, sh[-1])).tofile(mp)
+                lines.append("mesh %s %s" % (mesh_path, mp) if sh[0] == "mesh" else "%s %s %s" % (sh[0], " ".join(num(v) for v in sh[1:-1]), mp))
+            sp = os.path.join(tmp, "setup.scene")
+            open(sp, "w").write("\n".join(lines) + "\n")
+            run = lambda passes: json.loads(subprocess.check_output([O.REF_HARNESS, "time", sp, "-", str(W), str(H), str(spp), str(depth), str(cores),  # noqa: E731
+                                                                     str(passes), "tl"], stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            probe = run(1)
+            passes = int(max(2, min(200, budget_s / max(probe["mean_s"], 1e-3) * 0.5)))
+            res = run(passes)
+        return {"value": rays_per_frame / res["mean_s"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference", "ms_per_frame": res["mean_s"] * 1e3,
+                "sample": "%d full %dx%d passes of the reference's own translation units (oracle/_ref) over SetupScene's shapes, 10-row tasks, "
+                          "per-thread rand(); rays/frame taken from the GPU counters of the same frame" % (passes, W, H)}
+    s = O.Scene()
+    for sh in SHAPES:
+        i = {"sphere": lambda: s.add_sphere(sh[1], sh[2]), "plane": lambda: s.add_plane(sh[1], sh[2]),
+             "capsule": lambda: s.add_capsule(sh[1], sh[2], sh[3]), "mesh": lambda: s.add_mesh_obj(mesh_path)}[sh[0]]()
+        s.set_material(i, oracle_nodes(O, sh[-1]))
+    s.set_unitvec_mode(O.UNITVEC_F64)
+    fb = O.Framebuffer(W, H)
+    t = s.render_pass_pool(fb, depth, False, 0, spp, SEED, threads=cores, task_rows=TASK_ROWS)
+    passes = int(max(1, min(100, budget_s / max(t, 1e-3))))
+    O.stats_reset()
+    tt = 0.0
+    for p in range(passes):
+        tt += s.render_pass_pool(fb, depth, False, p + 1, spp, SEED, threads=cores, task_rows=TASK_ROWS)
+    st = O.stats_get()
+    return {"value": st["rays"] / tt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "ms_per_frame": tt / passes * 1e3,
+            "sample": "%d full %dx%d passes of the oracle port over SetupScene's shapes (10-row task pool)" % (passes, W, H)}
+
+
 def cpu_baseline(mesh_path, W, H, spp, depth, kind, rays_per_frame, budget_s=20.0):
     """The reference's CPU path on the host cores, bounded to roughly `budget_s` seconds of wall time."""
     from oracle import oracle as O
+    if kind == "setup":
+        return cpu_baseline_setup(mesh_path, W, H, spp, depth, rays_per_frame, budget_s)
     cores = O.hw_threads()
     harness = O.REF_HARNESS
     if os.path.exists(harness) and kind == "diffuse":
@@ -177,7 +240,11 @@ def main():
     ctx.set_option("path_lanes", args.path_lanes)
     ctx.set_option("path_variant", args.path_variant)
     scene = R.RayTracerScene(ctx)
-    scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
+    if kind == "setup":
+        from raytracerwin_amd.setup_scene import SetupScene
+        SetupScene(scene, mesh_path)
+    else:
+        scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
     scene.set_prune(args.prune)
     scene.set_traversal(args.traversal)
     scene.commit()
@@ -290,11 +357,13 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "Mrays/s (rays = closest-hit scene queries, primary + secondary) at 1920x1080 depth 4",
+            "metric": "Mrays/s (rays = closest-hit scene queries, primary + secondary) at %dx%d depth %d" % (W, H, depth),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": data,
-            "config": {"workload": "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s])"
+            "config": {"workload": ("RayTracerProgram::SetupScene (4 spheres, capsule, ground plane, %s.obj) %dx%d %d spp depth %d, reference camera "
+                                    "(the reference's default scene and window; not a BASELINE config)" % (mesh, W, H, spp, depth)) if kind == "setup" else
+                                   "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s])"
                                    % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3}[args.config]),
                        "sharding": "10-row tasks round-robin over ranks, one RCCL gather of the rows after the K passes",
                        "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "traversal": args.traversal, "packets": args.packets, "path_lanes": args.path_lanes},

@@ -35,6 +35,7 @@ public:
     float x, y, z;
     RVec3() : x(0.0f), y(0.0f), z(0.0f) {}
     RVec3(float _x, float _y, float _z) : x(_x), y(_y), z(_z) {}
+    RVec3 operator*(float s) const { return RVec3(x * s, y * s, z * s); }      // Src/RVector.h
 };
 
 struct RtwFailure : std::runtime_error {
@@ -157,6 +158,37 @@ public:
     int AddTo(rtw_scene* scene) const override { int idx = -1; RtwCheck(rtw_scene_add_mesh_obj(scene, Path.c_str(), &idx)); return idx; }
 private:
     std::string Path;
+};
+
+// RSphere / RPlane / RCapsule (Src/Shapes.h:46-112)
+class RSphere : public RShape {
+public:
+    RVec3 Center; float Radius;
+    RSphere(const RVec3& InCenter, float InRadius) : Center(InCenter), Radius(InRadius) {}
+    static std::unique_ptr<RSphere> Create(const RVec3& InCenter, float InRadius) { return std::unique_ptr<RSphere>(new RSphere(InCenter, InRadius)); }
+    int AddTo(rtw_scene* scene) const override { int idx = -1; const float c[3] = { Center.x, Center.y, Center.z }; RtwCheck(rtw_scene_add_sphere(scene, c, Radius, &idx)); return idx; }
+};
+class RPlane : public RShape {
+public:
+    RVec3 Normal, Point;
+    RPlane(const RVec3& InNormal, const RVec3& InPoint) : Normal(InNormal), Point(InPoint) {}
+    static std::unique_ptr<RShape> Create(const RVec3& InNormal, const RVec3& InPoint) { return std::unique_ptr<RShape>(new RPlane(InNormal, InPoint)); }
+    int AddTo(rtw_scene* scene) const override
+    {
+        int idx = -1; const float n[3] = { Normal.x, Normal.y, Normal.z }, q[3] = { Point.x, Point.y, Point.z };
+        RtwCheck(rtw_scene_add_plane(scene, n, q, &idx)); return idx;
+    }
+};
+class RCapsule : public RShape {
+public:
+    RVec3 Start, End; float Radius;
+    RCapsule(const RVec3& InStart, const RVec3& InEnd, float InRadius) : Start(InStart), End(InEnd), Radius(InRadius) {}
+    static std::unique_ptr<RShape> Create(const RVec3& InStart, const RVec3& InEnd, float InRadius) { return std::unique_ptr<RShape>(new RCapsule(InStart, InEnd, InRadius)); }
+    int AddTo(rtw_scene* scene) const override
+    {
+        int idx = -1; const float a[3] = { Start.x, Start.y, Start.z }, b[3] = { End.x, End.y, End.z };
+        RtwCheck(rtw_scene_add_capsule(scene, a, b, Radius, &idx)); return idx;
+    }
 };
 
 // ---- device context + frame buffers (accuBuffer[] / bitcolor[], Src/RayTracerProgram.cpp:49,77) ----------------------------------

@@ -88,3 +88,39 @@ def test_update_bitmap_pixels_loop_names_its_png_and_accumulates_like_pass_by_pa
     im = np.asarray(Image.open(os.path.join(str(tmp_path / "SavedImages"), pngs[0])))
     assert im.shape == (H, W, 3) and (im[..., 2].ravel() == cpp & 255).all()
     ctx.close()
+
+
+def test_default_scene_example_compiles_and_refuses_to_run_without_a_gpu(tmp_path):
+    import torch
+    exe = build_example(tmp_path, "default_scene")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, asset("unitychan.obj"), "1", "2", "32", "32"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_default_scene_example_equals_the_scene_built_through_the_python_mirror(tmp_path):
+    """examples/default_scene.cpp states RayTracerProgram::SetupScene (Src/RayTracerProgram.cpp:467-552) with the facade's RSphere /
+    RCapsule / RPlane / RMeshShape and renders it with UpdateBitmapPixels; the picture equals the same scene built from
+    tests/scenes.py (the description the reference-pinned fixtures were rendered from), accumulated pass by pass."""
+    import raytracerwin_amd as R
+    import scenes as SC
+    from oracle import oracle as O
+    exe = build_example(tmp_path, "default_scene")
+    W, H, N, D = 200, 200, 3, 6
+    raw = str(tmp_path / "o.argb")
+    subprocess.run([exe, asset("unitychan.obj"), str(N), str(D), str(W), str(H), raw], capture_output=True, text=True, cwd=str(tmp_path), check=True)
+    cpp = np.fromfile(raw, np.uint32)
+    ctx = R.Context(0)
+    s = R.RayTracerScene(ctx)
+    for sh in SC.default_scene():
+        mat = R.material_nodes_from_array(O.materials(sh[-1]))
+        shape = {"sphere": lambda: R.RSphere.Create(sh[1], sh[2]), "plane": lambda: R.RPlane.Create(sh[1], sh[2]),
+                 "capsule": lambda: R.RCapsule.Create(sh[1], sh[2], sh[3]), "mesh": lambda: R.RMeshShape.Create(asset(sh[1] + ".obj"))}[sh[0]]()
+        s.AddShape(shape, mat)
+    fb = R.Framebuffer(ctx, W, H)
+    for p in range(N):
+        R.ThreadWorker_Render(s, fb, 0, W * H - 1, D, None, p, 4, 12345)
+    assert (fb.resolve_argb() == cpp).all()
+    ctx.close()
