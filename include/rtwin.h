@@ -85,7 +85,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   second kernel on a side stream) + one wave-per-ray trace launch and one shade launch per bounce;
  *                   2 = packet walk for camera rays + a 16-lanes-per-ray trace and a shade launch per bounce;
  *                   1 = packet walk + one path kernel + resolve; 0 = one kernel, one thread per pixel.
- *   pipeline 3:     "direct_slots" (1) camera-ray hits are shaded by the primary kernel; "sky_split" (1) sky-only tiles
+ *   pipeline 3:     "direct_slots" (1) camera-ray hits are shaded by the primary kernel; "lead_split" (1) the scene's leading spheres / planes / capsules are tested by
+ *                   the lane that sets a segment up, the trace waves continue from its record; "sky_split" (1) sky-only tiles
  *                   in their own kernel; "wave_stage" (0) LDS staging of shape 0 in the trace kernels, 1..3 = levels /
  *                   leaves / triangles, -1 = as much as fits; "wave_fused" (0) one kernel carries the paths through all
  *                   bounces; "wave_tail" (0) one kernel after the first trace round; "wave_paths", "wave_blocks_mul",

@@ -938,6 +938,23 @@ __device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__
     return hit_shape;
 }
 
+// The first `lead` shapes of FindIntersectionWithScene for one ray per lane (they are spheres / planes / capsules): the same
+// tests in the same order on the same running distance; the query is continued from (seg, hit_shape, hit_slot, hit_pos).
+template <bool STATS>
+__device__ __forceinline__ void lead_find(const RtwSceneDev* __restrict__ sc, int lead, const Ray& in, float& seg, int& hit_shape, int& hit_slot, f3& hit_pos, Counters& ct)
+{
+    for (int s = 0; s < lead; s++) {
+        const RtwShapeDev& sh = sc->shapes[s];
+        if (sh.kind != RTW_SHAPE_PLANE) {
+            float t0, t1;
+            if (STATS) ct.boxes++;
+            if (!slab_exact(in, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+        }
+        f3 pos; float dist; int part;
+        if (analytic_test(sh, in, seg, pos, dist, part)) { seg = dist; hit_shape = s; hit_slot = part; hit_pos = pos; }
+    }
+}
+
 // ---- materials (Src/SurfaceMaterials.cpp:20-187), flattened tree, explicit evaluation stack -------------
 struct Bounce { f3 att, em; };
 
@@ -1651,6 +1668,32 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
     pb.state[(size_t)q * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
     pb.state[(size_t)q * 3 + 2] = make_float4(__uint_as_float(rng.key), __uint_as_float(rng.table_reads),
                                               __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
+    if (p.lead_shapes > 0) {        // the scene's leading spheres / planes / capsules: tested here, a ray per lane (in the trace kernel a whole
+                                    // wave would repeat each test 64 times); the record is where the trace of this segment starts from
+        int hs = -1, hslot = -1; f3 hp = mk(0, 0, 0); float seg = ray.dist;
+        lead_find<STATS>(sc, p.lead_shapes, ray, seg, hs, hslot, hp, ct);
+        // can a later shape be hit at all?  Only if the ray's line meets its culling box (the reference's own early-out,
+        // Src/RayTracerScene.cpp:109; a plane has none).  If no box is met the record above is the query's result.
+        // With pruning on, a tame ray whose segment [0, seg] ends before the box or starts past it cannot be accepted by anything
+        // inside either (the walk's own conservative cull, with its margins, applied to the shape's box: skipped tests are tests
+        // the reference runs and rejects).
+        const int n_shapes = sc->n_shapes;
+        bool more = false; uint32_t tested = 0u;
+        const bool cull = sc->prune != 0 && ray_is_tame(ray);
+        const float eps_t = 2.0e-5f * fmaxf(fabsf(1.0f / ray.d.x), fmaxf(fabsf(1.0f / ray.d.y), fabsf(1.0f / ray.d.z)));
+        for (int s = p.lead_shapes; s < n_shapes; s++) {
+            const RtwShapeDev& sh = sc->shapes[s];
+            float t0, t1;
+            if (sh.kind == RTW_SHAPE_PLANE) { more = true; continue; }
+            tested++;
+            if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+            if (cull && sh.kind == RTW_SHAPE_MESH && (t0 > seg + (eps_t + 1.0e-4f * seg) || t1 < -eps_t)) continue;     // (meshes only: their walk applies the same cull)
+            more = true;
+        }
+        if (STATS && !more) { ct.rays++; ct.boxes += tested; }       // (a ray that goes on to the trace kernel is counted there)
+        pb.hitslot[(size_t)q * 2] = make_float4(hp.x, hp.y, hp.z, seg);
+        pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(more ? 1 : 0), 0.0f);
+    }
     return true;
 }
 
@@ -1963,7 +2006,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
             return items > owners ? (long long)owners : items;
         };
         for (int r = p.direct_slots ? 1 : 0; r < p.max_bounce; r++) {      // direct slots: the primary kernel was shade(0)
-            if (r > 0) {
+            if (r > 0 && !tune.skip_trace) {
                 const long long rays = items_of(r);
                 const int stage = tune.wave_stage;
 #define RTW_LAUNCH_TW(ST, NTV)                                                                                                                  \
@@ -1977,6 +2020,18 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                     else { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<false, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
                         hipLaunchKernelGGL((trace_wave_kernel<false, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
                 } while (0)
+                if (p.lead_shapes > 0) {        // leading analytic shapes: the records are half done, most rays need no trace (see trace_wave_lead_kernel)
+                    constexpr int NTV = 128;
+                    int shift = 0;
+                    while (shift < 6 && (rays >> (shift + 1)) >= 16384) shift++;
+                    long long blocks = ((rays >> shift) + NTV / 64) / (NTV / 64);
+                    const long long cap = (long long)tune.wave_blocks * (1024 / NTV) * tune.wave_blocks_mul;
+                    if (blocks < 1) blocks = 1;
+                    if (blocks > cap) blocks = cap;
+                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
+                    if (stats) hipLaunchKernelGGL((trace_wave_lead_kernel<true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
+                    else hipLaunchKernelGGL((trace_wave_lead_kernel<false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
+                } else
                 if (stage == 0 && tune.trace_block == 64) RTW_LAUNCH_TW(0, 64); else if (stage == 0 && tune.trace_block == 128) RTW_LAUNCH_TW(0, 128); else if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
 #undef RTW_LAUNCH_TW
             }

@@ -131,7 +131,9 @@ struct RtwRenderParams {
     int32_t pad_params;
     int32_t direct_slots;           // bins + wave pipeline: the primary kernel shades the camera rays' hits itself; a path's slot in the
                                     // dense arrays is work item * sub_samples + sub-sample (no queue), pb.queue is round 0's trace list
-    int32_t pad_direct;
+    int32_t lead_shapes;            // bins + wave pipeline with direct slots: the scene's first lead_shapes shapes are spheres / planes / capsules;
+                                    // the lane that sets up a path's next segment (shade_hit_step) tests them there, one ray per lane, and
+                                    // leaves the partial scene query in the path's hit record; the wave-per-ray trace continues from it
     int32_t self_clean;             // resolve_kernel files the counters at word 64.. and zeroes them for the next pass
     int32_t n_jobs;                 // entries of tile_order
     const struct RtwBinsDev* bins;  // [n_shapes] or null

@@ -198,12 +198,14 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
 // FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) of one ray held by the whole wave, without the shading
 // tail (only the record of the last shape that hit is read afterwards).  `shape0` describes shape 0 (its arrays staged
 // in LDS when STAGE > 0); later shapes are read from the scene.
+// The query covers shapes [first_shape, n_shapes) and continues from the caller's (hit_shape, hit_slot, hit_pos, seg): for a fresh
+// query that is (-1, -1, 0, ray.dist) with first_shape 0; with leading analytic shapes already tested by the shading lane
+// (RtwRenderParams::lead_shapes) it is that partial result.
 template <bool STATS, int STAGE>
-__device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __restrict__ sc, int n_shapes, bool prune, const FlatSrc& shape0,
+__device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __restrict__ sc, int first_shape, int n_shapes, bool prune, const FlatSrc& shape0,
                                                        uint32_t* __restrict__ lds, const Ray& ray,
                                                        int& hit_shape, int& hit_slot, f3& hit_pos, float& seg, Counters& ct)
 {
-    hit_shape = -1; hit_slot = -1; hit_pos = mk(0, 0, 0); seg = ray.dist;
     const bool one = lane_id() == 0;
     if (STATS && one) ct.rays++;
     const bool tame = ray_is_tame(ray);
@@ -212,7 +214,7 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
     fr.skx = near_zero(ray.d.x); fr.sky = near_zero(ray.d.y); fr.skz = near_zero(ray.d.z);
     fr.ix = (!tame && fr.skx) ? 0.0f : 1.0f / ray.d.x; fr.iy = (!tame && fr.sky) ? 0.0f : 1.0f / ray.d.y; fr.iz = (!tame && fr.skz) ? 0.0f : 1.0f / ray.d.z;
     fr.eps_t = 2.0e-5f * fmaxf(fabsf(fr.ix), fmaxf(fabsf(fr.iy), fabsf(fr.iz)));
-    for (int s = 0; s < n_shapes; s++) {
+    for (int s = first_shape; s < n_shapes; s++) {
         const FlatSrc g = (s == 0) ? shape0 : flat_src_of(sc->shapes[s]);
         const int kind = sc->shapes[s].kind;
         if (kind == RTW_SHAPE_PLANE) {      // no culling box (RPlane::HasCullingBounds); every lane computes the one ray's test alike
@@ -553,11 +555,55 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trac
         const int q = (int)cldu(src, ku);
         const float4 s0 = cld4(pb.state, q * 3), s1 = cld4(pb.state, q * 3 + 1);
         Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
-        int hs, slot; f3 pos; float seg;
-        wave_find_intersection<STATS, STAGE>(sc, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
+        int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
+        wave_find_intersection<STATS, STAGE>(sc, 0, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
         if (lane_id() == 0) {
             pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
+        }
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+// The trace step of a scene whose leading shapes are analytic (RtwRenderParams::lead_shapes > 0).  The lane that set a segment up
+// has tested those shapes and, with the reference's own culling test, the boxes of the shapes after them; a ray that meets none
+// of those boxes has its complete record already (flag word 0) and is passed over here.  A wave takes 2^chunk_shift list entries
+// at a time -- lane j reads entry j's flag -- and runs the wave-per-ray query for the flagged ones only.
+template <bool STATS, int NT>
+__global__ __launch_bounds__(NT) void trace_wave_lead_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int chunk_shift)
+{
+    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
+    const bool from_queue = p.direct_slots && round == 0;
+    const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round];
+    const uint32_t chunk = 1u << chunk_shift;
+    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) * chunk >= n) return;
+    uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
+    const FlatSrc staged = flat_src_of(sc->shapes[0]);
+    const uint32_t* __restrict__ src = from_queue ? pb.queue : wf_list(pb, round & 1);
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);
+    const uint32_t lane = (uint32_t)lane_id();
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t c = wave; (unsigned long long)c * chunk < n; c += nwaves) {
+        const uint32_t k = c * chunk + lane;
+        const bool mine = lane < chunk && k < n;
+        const uint32_t qm = mine ? src[k] : 0u;
+        const bool need = mine && qm < pb.capacity && __float_as_int(pb.hitslot[(size_t)qm * 2 + 1].z) != 0;
+        unsigned long long todo = __ballot(need);
+        while (todo != 0ull) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int q = __builtin_amdgcn_readlane((int)qm, l);
+            const float4 s0 = cld4(pb.state, q * 3), s1 = cld4(pb.state, q * 3 + 1);
+            Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+            const float4 h0 = cld4(pb.hitslot, q * 2), h1 = cld4(pb.hitslot, q * 2 + 1);
+            f3 pos = mk(h0.x, h0.y, h0.z); float seg = h0.w; int hs = __float_as_int(h1.x), slot = __float_as_int(h1.y);
+            wave_find_intersection<STATS, 0>(sc, p.lead_shapes, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
+            if (lane == 0u) {
+                pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
+                pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
+            }
         }
     }
     if (STATS) flush_counters(sc, ct);
@@ -684,7 +730,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
                 ur.d = mk(readlane_f(ray.d.x, l), readlane_f(ray.d.y, l), readlane_f(ray.d.z, l));
                 ur.dist = readlane_f(ray.dist, l);
                 int hs, slot; f3 pos; float seg;
-                wave_find_intersection<STATS, STAGE>(sc, n_shapes, prune, staged, lds, ur, hs, slot, pos, seg, ct);
+                hs = -1; slot = -1; pos = mk(0, 0, 0); seg = ur.dist;
+                wave_find_intersection<STATS, STAGE>(sc, 0, n_shapes, prune, staged, lds, ur, hs, slot, pos, seg, ct);
                 if (lane == l) {
                     r0 = make_float4(pos.x, pos.y, pos.z, seg);
                     r1 = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);

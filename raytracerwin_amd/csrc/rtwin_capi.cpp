@@ -61,6 +61,7 @@ struct rtw_context {
     bool own_stream = false;
     hipStream_t aux_stream = nullptr;   // sky-only tiles of the bins + wave pipeline run here, beside the main stream
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    int lead_split = 1;                 // pipeline 3: leading analytic shapes are tested by the shading lanes (0: by the trace waves, for comparison)
     int direct_slots = 1;               // pipeline 3: the primary kernel shades the camera rays' hits itself (no shade(0) launch, no queue)
     int sky_split = 1;                  // 0 = one primary kernel for every tile
     float* d_unit = nullptr;
@@ -259,6 +260,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "lead_split") == 0) { ctx->lead_split = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "sky_split") == 0) { ctx->sky_split = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "use_graph") == 0) { ctx->use_graph = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "primary_blocks_per_cu") == 0) {
@@ -1005,6 +1007,12 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         const size_t coff = rtw::pipeline_counters_offset(p.count, max_bounce);
         p.self_clean = p.wavefront == 2 ? 1 : 0;
         p.direct_slots = (p.wavefront == 2 && cx->direct_slots && !cx->wave_fused && !cx->wave_tail) ? 1 : 0;
+        {   // leading spheres / planes / capsules are tested by the lane that sets a segment up (see RtwRenderParams::lead_shapes)
+            int lead = 0;
+            while (lead < (int)scene->meshes.size() && scene->meshes[(size_t)lead]->kind != RTW_SHAPE_MESH) lead++;
+            p.lead_shapes = (p.direct_slots && cx->lead_split) ? lead : 0;
+            tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();       // nothing is left for the trace kernels
+        }
         tune.counters_clean = p.self_clean && cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
         cx->clean_ws = nullptr;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
