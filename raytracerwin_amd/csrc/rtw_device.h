@@ -35,6 +35,7 @@ struct PipelineTuning {
     // bins + wave pipeline: jobs [sky_job0, n_jobs) of the job table are sky-only tiles, rendered by primary_sky_kernel on aux_stream
     // between the two events (fork after the previous work of the main stream, join before the pass ends); aux_stream null = one kernel
     hipStream_t aux_stream; hipEvent_t fork_event, join_event; int sky_job0; const float* gamma_thr;
+    bool has_analytic = false;  // some shape is a sphere / plane / capsule: the kernels' instantiations that hold those tests are launched
     bool skip_trace = false;    // every shape is a leading analytic shape: the shading lanes do the whole scene query, no trace launches
     bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
     int trace_block;       // threads per block of the unstaged trace kernel: 256 (default), 128 or 64

@@ -1608,7 +1608,7 @@ __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32
 // the next segment; or finish the path (fold the levels back in the reference's association order, write the radiance).
 // have_hit false: nothing to shade yet (the segment still has to be traced).  Returns true when the path goes on: its
 // state is then saved in slot q.
-template <bool STATS>
+template <bool STATS, bool AN>
 __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ sc, const PipeBufs& pb, const RtwRenderParams& p, uint32_t q, uint32_t pid,
                                                Ray ray, PathRng rng, int depth, int nlev, bool have_hit, float4 r0, float4 r1, Counters& ct)
 {
@@ -1623,7 +1623,8 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
         else {
             const RtwShapeDev& sh = sc->shapes[hs];
             Hit h; int tri_index;
-            hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+            if (AN) hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+            else mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
             if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
             else {
                 Ray out = ray;
@@ -1668,7 +1669,7 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
     pb.state[(size_t)q * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
     pb.state[(size_t)q * 3 + 2] = make_float4(__uint_as_float(rng.key), __uint_as_float(rng.table_reads),
                                               __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
-    if (p.lead_shapes > 0) {        // the scene's leading spheres / planes / capsules: tested here, a ray per lane (in the trace kernel a whole
+    if (AN && p.lead_shapes > 0) {  // the scene's leading spheres / planes / capsules: tested here, a ray per lane (in the trace kernel a whole
                                     // wave would repeat each test 64 times); the record is where the trace of this segment starts from
         int hs = -1, hslot = -1; f3 hp = mk(0, 0, 0); float seg = ray.dist;
         lead_find<STATS>(sc, p.lead_shapes, ray, seg, hs, hslot, hp, ct);
@@ -1697,7 +1698,7 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
     return true;
 }
 
-template <bool STATS>
+template <bool STATS, bool AN>
 __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
     // the round's input list: round 0 = the path queue itself; with direct slots the queue is round 0's TRACE list (round 1's input)
@@ -1740,7 +1741,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
                 const size_t rec = (round == 0 && p.wavefront == 2) ? (size_t)pid : (size_t)q;
                 r0 = pb.hitslot[rec * 2]; r1 = pb.hitslot[rec * 2 + 1];
             }
-            go_on = shade_hit_step<STATS>(sc, pb, p, q, pid, ray, rng, depth, nlev, have_hit, r0, r1, ct);
+            go_on = shade_hit_step<STATS, AN>(sc, pb, p, q, pid, ray, rng, depth, nlev, have_hit, r0, r1, ct);
         }
         wave_push(dst, &pb.counters[4 + round], go_on, q);
     }
@@ -1987,8 +1988,13 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         const RtwRenderParams& p = ph;      // the bins kernel takes the jobs the sky kernel does not
         const int jobs_grid = p.tile_order ? (p.n_jobs + 3) / 4 : grid;        // a wave per job (a tile, or a tile's sub-sample)
         const int pgrid = jobs_grid < tune.wave_blocks * tune.primary_blocks_per_cu ? jobs_grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // else waves take jobs in turn
-        if (stats) hipLaunchKernelGGL(primary_bins_kernel<true>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-        else hipLaunchKernelGGL(primary_bins_kernel<false>, dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        if (tune.has_analytic) {
+            if (stats) hipLaunchKernelGGL((primary_bins_kernel<true, true>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+            else hipLaunchKernelGGL((primary_bins_kernel<false, true>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        } else {
+            if (stats) hipLaunchKernelGGL((primary_bins_kernel<true, false>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+            else hipLaunchKernelGGL((primary_bins_kernel<false, false>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+        }
     } else if (p.packets) {
         if (stats) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
         else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
@@ -2031,6 +2037,15 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                     const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
                     if (stats) hipLaunchKernelGGL((trace_wave_lead_kernel<true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
                     else hipLaunchKernelGGL((trace_wave_lead_kernel<false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
+                } else if (tune.has_analytic) { // analytic shapes somewhere after a mesh: the general wave-per-ray query
+                    constexpr int NTV = 128;
+                    long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);
+                    const long long cap = (long long)tune.wave_blocks * (1024 / NTV) * tune.wave_blocks_mul;
+                    if (blocks < 1) blocks = 1;
+                    if (blocks > cap) blocks = cap;
+                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
+                    if (stats) hipLaunchKernelGGL((trace_wave_kernel<true, 0, NTV, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
+                    else hipLaunchKernelGGL((trace_wave_kernel<false, 0, NTV, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
                 } else
                 if (stage == 0 && tune.trace_block == 64) RTW_LAUNCH_TW(0, 64); else if (stage == 0 && tune.trace_block == 128) RTW_LAUNCH_TW(0, 128); else if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
 #undef RTW_LAUNCH_TW
@@ -2062,8 +2077,13 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
             long long sb = (items_of(r) + 255) / 256;
             if (sb < 1) sb = 1;
             if (sb > 262144) sb = 262144;
-            if (stats) hipLaunchKernelGGL(shade_kernel<true>, dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
-            else hipLaunchKernelGGL(shade_kernel<false>, dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+            if (tune.has_analytic) {
+                if (stats) hipLaunchKernelGGL((shade_kernel<true, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+                else hipLaunchKernelGGL((shade_kernel<false, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+            } else {
+                if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+                else hipLaunchKernelGGL((shade_kernel<false, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+            }
         }
     } else if (p.wavefront == 2) {
         // one wave per p.wave_paths queued paths; blocks past the real queue leave at once
@@ -2110,8 +2130,8 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                 else hipLaunchKernelGGL(trace_kernel<false>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
             }
             const int sb = size_for(r, 1);
-            if (stats) hipLaunchKernelGGL(shade_kernel<true>, dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
-            else hipLaunchKernelGGL(shade_kernel<false>, dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
+            if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r);      // (scenes with analytic shapes never take this pipeline)
+            else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
         }
     } else if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
         constexpr int NT = 256;         // experiment: no register cap (2 waves/SIMD), staged tree per 4 waves

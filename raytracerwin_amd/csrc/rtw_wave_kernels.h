@@ -201,7 +201,8 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
 // The query covers shapes [first_shape, n_shapes) and continues from the caller's (hit_shape, hit_slot, hit_pos, seg): for a fresh
 // query that is (-1, -1, 0, ray.dist) with first_shape 0; with leading analytic shapes already tested by the shading lane
 // (RtwRenderParams::lead_shapes) it is that partial result.
-template <bool STATS, int STAGE>
+// AN = the scene may hold spheres / planes / capsules; mesh-only scenes run instantiations without that code (registers, occupancy).
+template <bool STATS, int STAGE, bool AN>
 __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __restrict__ sc, int first_shape, int n_shapes, bool prune, const FlatSrc& shape0,
                                                        uint32_t* __restrict__ lds, const Ray& ray,
                                                        int& hit_shape, int& hit_slot, f3& hit_pos, float& seg, Counters& ct)
@@ -216,8 +217,8 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
     fr.eps_t = 2.0e-5f * fmaxf(fabsf(fr.ix), fmaxf(fabsf(fr.iy), fabsf(fr.iz)));
     for (int s = first_shape; s < n_shapes; s++) {
         const FlatSrc g = (s == 0) ? shape0 : flat_src_of(sc->shapes[s]);
-        const int kind = sc->shapes[s].kind;
-        if (kind == RTW_SHAPE_PLANE) {      // no culling box (RPlane::HasCullingBounds); every lane computes the one ray's test alike
+        const int kind = AN ? sc->shapes[s].kind : RTW_SHAPE_MESH;
+        if (AN && kind == RTW_SHAPE_PLANE) {      // no culling box (RPlane::HasCullingBounds); every lane computes the one ray's test alike
             f3 pos; float dist; int part;
             if (analytic_test(sc->shapes[s], ray, seg, pos, dist, part)) { seg = dist; hit_shape = s; hit_slot = part; hit_pos = pos; }
             continue;
@@ -238,7 +239,7 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
         if (!in_bound) continue;
         float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
         bool any;
-        if (kind != RTW_SHAPE_MESH) {       // a sphere or a capsule: the record's slot says which part was hit
+        if (AN && kind != RTW_SHAPE_MESH) { // a sphere or a capsule: the record's slot says which part was hit
             any = analytic_test(sc->shapes[s], ray, seg, pos, cur, slot);
         } else if (g.n[0] > 0) {
             if (tame) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void primary_sky_kernel(const float* __restric
 }
 
 // ---- primary rays through the screen bins ------------------------------------------------------------------------
-template <bool STATS>
+template <bool STATS, bool AN>
 __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
                                                            uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
 {
@@ -373,16 +374,16 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
             const bool skx = near_zero(ray.d.x), sky = near_zero(ray.d.y), skz = near_zero(ray.d.z);
             for (int k = 0; k < n_shapes; k++) {
                 const RtwShapeDev& sh = sc->shapes[k];
-                const int kind = sh.kind;
+                const int kind = AN ? sh.kind : RTW_SHAPE_MESH;
                 float t0, t1;
-                const bool inbox = live && (kind == RTW_SHAPE_PLANE ||      // a plane has no culling box (RPlane::HasCullingBounds)
+                const bool inbox = live && ((AN && kind == RTW_SHAPE_PLANE) ||      // a plane has no culling box (RPlane::HasCullingBounds)
                                             slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1));
                 if (STATS && live && kind != RTW_SHAPE_PLANE) ct.boxes++;
                 if (__ballot(inbox) == 0ull) continue;
                 float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
                 bool any = false;
                 const uint32_t* __restrict__ boff = p.bins[k].off;
-                if (kind != RTW_SHAPE_MESH) {                // a sphere / plane / capsule: every lane tests its own ray; slot = the part hit
+                if (AN && kind != RTW_SHAPE_MESH) {          // a sphere / plane / capsule: every lane tests its own ray; slot = the part hit
                     if (inbox) any = analytic_test(sh, ray, seg, pos, cur, slot);
                 } else if (boff == nullptr) {                // no bins for this shape: packet walk of its tree
                     any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         if (live && (near_wave || only_sample >= 0) && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
         if (queue_it && p.direct_slots) {                    // shade the hit here: the path's slot needs no queue position
             hit_any = true;
-            if (shade_hit_step<STATS>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, true, hr0, hr1, ct))
+            if (shade_hit_step<STATS, AN>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, true, hr0, hr1, ct))
                 queued |= 1u << i;                           // it goes on: its slot joins round 0's trace list below
         } else if (queue_it) {                               // the hit record waits under the path id; the queue entry follows below
             hit_any = true;
@@ -536,7 +537,7 @@ __device__ __forceinline__ FlatSrc stage_shape0(const RtwSceneDev* __restrict__ 
 // ---- one round of secondary segments: a wave per ray -----------------------------------------------------------------
 // The wavefront pipeline's trace step (see trace_kernel) with the whole wave on one ray: the ray comes in through scalar
 // loads, the walk is wave_walk_flat on the arrays the block staged in LDS.  Persistent blocks, one per CU when staged.
-template <bool STATS, int STAGE, int NT>
+template <bool STATS, int STAGE, int NT, bool AN = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trac
         const float4 s0 = cld4(pb.state, q * 3), s1 = cld4(pb.state, q * 3 + 1);
         Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
-        wave_find_intersection<STATS, STAGE>(sc, 0, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
+        wave_find_intersection<STATS, STAGE, AN>(sc, 0, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
         if (lane_id() == 0) {
             pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(NT) void trace_wave_lead_kernel(const RtwSceneDev* 
             Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
             const float4 h0 = cld4(pb.hitslot, q * 2), h1 = cld4(pb.hitslot, q * 2 + 1);
             f3 pos = mk(h0.x, h0.y, h0.z); float seg = h0.w; int hs = __float_as_int(h1.x), slot = __float_as_int(h1.y);
-            wave_find_intersection<STATS, 0>(sc, p.lead_shapes, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
+            wave_find_intersection<STATS, 0, true>(sc, p.lead_shapes, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
             if (lane == 0u) {
                 pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
                 pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathw
                 ur.dist = readlane_f(ray.dist, l);
                 int hs, slot; f3 pos; float seg;
                 hs = -1; slot = -1; pos = mk(0, 0, 0); seg = ur.dist;
-                wave_find_intersection<STATS, STAGE>(sc, 0, n_shapes, prune, staged, lds, ur, hs, slot, pos, seg, ct);
+                wave_find_intersection<STATS, STAGE, true>(sc, 0, n_shapes, prune, staged, lds, ur, hs, slot, pos, seg, ct);
                 if (lane == l) {
                     r0 = make_float4(pos.x, pos.y, pos.z, seg);
                     r1 = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);

@@ -1011,6 +1011,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
             int lead = 0;
             while (lead < (int)scene->meshes.size() && scene->meshes[(size_t)lead]->kind != RTW_SHAPE_MESH) lead++;
             p.lead_shapes = (p.direct_slots && cx->lead_split) ? lead : 0;
+            tune.has_analytic = scene->has_analytic;
             tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();       // nothing is left for the trace kernels
         }
         tune.counters_clean = p.self_clean && cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
