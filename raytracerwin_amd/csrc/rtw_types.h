@@ -67,7 +67,7 @@ struct RtwMaterialNode {    // mirrors rtw_material_node
 
 #define RTW_DEV_MAX_TEXTURES 64
 #define RTW_DEV_MAX_MATERIAL_NODES 64
-#define RTW_DEV_MAX_SHAPES 8
+#define RTW_DEV_MAX_SHAPES 32
 #define RTW_SHAPE_MESH 0
 #define RTW_SHAPE_SPHERE 1
 #define RTW_SHAPE_PLANE 2

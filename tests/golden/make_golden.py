@@ -187,7 +187,7 @@ def golden_scene_frame(name, tag, W, Hh, ns, depth, preview, seed, pass0, npass,
 
 def main_scenes(tmp, rng, bounds):
     """multi-shape scenes: RSphere / RPlane / RCapsule beside meshes (tests/scenes.py)"""
-    for tag in ("default_nofuzz", "quirk", "shapes"):
+    for tag in ("default_nofuzz", "quirk", "shapes", "room"):
         golden_scene_closest(tag, 700, tmp, rng, bounds)
     S = golden_scene_frame
     S("default_d5", "default", 80, 80, 4, 5, 0, 12345, 0, 1, tmp)
@@ -197,6 +197,7 @@ def main_scenes(tmp, rng, bounds):
     S("quirk_preview", "quirk", 96, 96, 4, 4, 1, 77, 0, 1, tmp)
     S("shapes_d6", "shapes", 96, 64, 4, 6, 0, 9, 1, 2, tmp)
     S("shapes_1spp_d2", "shapes", 50, 70, 1, 2, 0, 9, 0, 1, tmp)
+    S("room_d8", "room", 64, 64, 4, 8, 0, 21, 0, 1, tmp)
 
 
 def main():

@@ -86,7 +86,22 @@ def shapes_scene():
     ]
 
 
-SCENES = {"default": lambda: default_scene(True), "default_nofuzz": lambda: default_scene(False),
+def room_scene():
+    """SetupScene's shapes inside the room its source keeps commented out (ceiling light sphere, ceiling, back / front / right / left
+    walls): 13 shapes, planes after the mesh (those are tested by the trace waves), an emissive light, a plane behind the camera."""
+    room = [
+        ("sphere", (0.0, 5.0, 0.0), 0.5, emissive((5.0, 2.0, 6.0))),
+        ("plane", (0.0, -1.0, 0.0), (0.0, 5.0, 0.0), diffuse((1.2, 1.2, 1.5))),
+        ("plane", (0.0, 0.0, 1.0), (0.0, 0.0, -5.0), checker()),
+        ("plane", (0.0, 0.0, -1.0), (0.0, 0.0, 10.0), checker()),
+        ("plane", (1.0, 0.0, 0.0), (-5.0, 0.0, 0.0), checker()),
+        ("plane", (-1.0, 0.0, 0.0), (5.0, 0.0, 0.0), checker()),
+    ]
+    d = default_scene(False)
+    return d[:6] + room[:3] + [("mesh", "TorusKnot", diffuse((0.9, 0.9, 0.9)))] + room[3:] + d[6:7]
+
+
+SCENES = {"room": room_scene, "default": lambda: default_scene(True), "default_nofuzz": lambda: default_scene(False),
           "quirk": quirk_scene, "shapes": shapes_scene}
 
 
