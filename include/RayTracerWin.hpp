@@ -191,6 +191,19 @@ public:
     }
 };
 
+class RTriangle : public RShape {
+public:
+    RVec3 Points[3];
+    RTriangle(const RVec3& p0, const RVec3& p1, const RVec3& p2) { Points[0] = p0; Points[1] = p1; Points[2] = p2; }
+    static std::unique_ptr<RShape> Create(const RVec3& p0, const RVec3& p1, const RVec3& p2) { return std::unique_ptr<RShape>(new RTriangle(p0, p1, p2)); }
+    int AddTo(rtw_scene* scene) const override
+    {
+        int idx = -1; float p[3][3];
+        for (int i = 0; i < 3; i++) { p[i][0] = Points[i].x; p[i][1] = Points[i].y; p[i][2] = Points[i].z; }
+        RtwCheck(rtw_scene_add_triangle(scene, p[0], p[1], p[2], &idx)); return idx;
+    }
+};
+
 // ---- device context + frame buffers (accuBuffer[] / bitcolor[], Src/RayTracerProgram.cpp:49,77) ----------------------------------
 class RtwDevice {
 public:

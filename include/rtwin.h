@@ -117,6 +117,9 @@ int rtw_scene_add_mesh_obj(rtw_scene* scene, const char* obj_path, int* out_shap
 int rtw_scene_add_sphere(rtw_scene* scene, const float center[3], float radius, int* out_shape);
 int rtw_scene_add_plane(rtw_scene* scene, const float normal[3], const float point[3], int* out_shape);
 int rtw_scene_add_capsule(rtw_scene* scene, const float start[3], const float end[3], float radius, int* out_shape);
+/* RTriangle::Create(p0, p1, p2) (Src/Shapes.h:106-130): one single-sided triangle with its face normal, culled by the box of its
+ * three points (so an axis-aligned one is as invisible as the reference's: its zero-thickness box never passes the slab test). */
+int rtw_scene_add_triangle(rtw_scene* scene, const float p0[3], const float p1[3], const float p2[3], int* out_shape);
 /* Same, from arrays the caller already holds (the members of RMeshShape,
  * Src/MeshShape.h:25-37).  positions/texcoords/normals are 3 floats per element,
  * idx_* are 3 ints per triangle (0-based), tri_material is 1 int per triangle (-1 = none).

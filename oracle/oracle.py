@@ -120,6 +120,10 @@ class Scene:
     def add_capsule(self, start, end, radius):
         return lib().orc_scene_add_capsule(self.h, _p(np.asarray(start, np.float32)), _p(np.asarray(end, np.float32)), C.c_float(radius))
 
+    def add_triangle(self, p0, p1, p2):
+        f = lambda v: _p(np.asarray(v, np.float32))  # noqa: E731
+        return lib().orc_scene_add_triangle(self.h, f(p0), f(p1), f(p2))
+
     def add_shapes(self, scene, asset_path):
         """scene: a list from tests/scenes.py; asset_path(name) -> OBJ path"""
         for sh in scene:
@@ -129,6 +133,8 @@ class Scene:
                 i = self.add_plane(sh[1], sh[2])
             elif sh[0] == "capsule":
                 i = self.add_capsule(sh[1], sh[2], sh[3])
+            elif sh[0] == "triangle":
+                i = self.add_triangle(sh[1], sh[2], sh[3])
             else:
                 i = self.add_mesh_obj(asset_path(sh[1]))
             if sh[-1] is not None:

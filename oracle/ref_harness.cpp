@@ -184,7 +184,7 @@ static std::unique_ptr<ISurfaceMaterial> material_arg(const char* matfile, bool 
 }
 
 // A ".scene" file lists the shapes in insertion order, one per line (numbers are decimal renderings of exact floats):
-//   sphere cx cy cz r MAT | plane nx ny nz px py pz MAT | capsule sx sy sz ex ey ez r MAT | mesh OBJ MAT
+//   sphere cx cy cz r MAT | plane nx ny nz px py pz MAT | capsule sx sy sz ex ey ez r MAT | triangle 9 numbers MAT | mesh OBJ MAT
 // MAT = a material-node file, "-" (Diffuse(1,1,1)) or "none" (no material).  The shapes are made by the reference's own
 // RSphere / RPlane / RCapsule / RMeshShape::Create and added with RayTracerScene::AddShape.
 static void setup_scene_file(const char* path)
@@ -203,6 +203,11 @@ static void setup_scene_file(const char* path)
         } else if (!strcmp(kind, "capsule")) {
             if (fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %4095s", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], m) != 8) exit(2);
             g_program->GetScene()->AddShape(RCapsule::Create(RVec3((float)v[0], (float)v[1], (float)v[2]), RVec3((float)v[3], (float)v[4], (float)v[5]), (float)v[6]), material_arg(m, true));
+        } else if (!strcmp(kind, "triangle")) {
+            double w[9];
+            if (fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %4095s", &w[0], &w[1], &w[2], &w[3], &w[4], &w[5], &w[6], &w[7], &w[8], m) != 10) exit(2);
+            g_program->GetScene()->AddShape(RTriangle::Create(RVec3((float)w[0], (float)w[1], (float)w[2]), RVec3((float)w[3], (float)w[4], (float)w[5]),
+                                                              RVec3((float)w[6], (float)w[7], (float)w[8])), material_arg(m, true));
         } else if (!strcmp(kind, "mesh")) {
             if (fscanf(f, "%4095s %4095s", a, m) != 2) exit(2);
             auto mesh = RMeshShape::Create(a);

@@ -419,6 +419,7 @@ typedef struct {
     aabb_t aabb;            /* RShape::Aabb */
     int has_culling_bounds;
     int kind;               /* ORC_SHAPE_* */
+    vec3 c;                 /* triangle: a, b, c = Points[0..2] (Src/Shapes.h:106-130) */
     vec3 a, b;              /* sphere: a = Center; plane: a = Normal, b = Point; capsule: a = Start, b = End (Src/Shapes.h:46-112) */
     float radius;
     mesh_t* mesh;
@@ -775,6 +776,7 @@ static int shape_test_ray(const shape_t* s, const ray_t* r, hit_t* out, int* tri
     case ORC_SHAPE_SPHERE: if (!ray_test_sphere(r, s->a, s->radius, out)) return 0; break;
     case ORC_SHAPE_PLANE: if (!ray_test_plane(r, s->a, s->b, out)) return 0; break;
     case ORC_SHAPE_CAPSULE: if (!ray_test_capsule(r, s->a, s->b, s->radius, out)) return 0; break;
+    case ORC_SHAPE_TRIANGLE: { vec3 t[3] = { s->a, s->b, s->c }; if (!ray_test_triangle(r, t, out)) return 0; break; }   /* RTriangle::TestRayIntersection (Src/Shapes.cpp:127-130) */
     default: return 0;
     }
     if (tri_out) *tri_out = -1;     /* (this API's convention: no triangle index for an analytic shape) */
@@ -1208,6 +1210,14 @@ int orc_scene_add_capsule(orc_scene* sc, const float start[3], const float end[3
     s.a = v3(start[0], start[1], start[2]); s.b = v3(end[0], end[1], end[2]); s.radius = radius;
     aabb_expand_by_sphere(&s.aabb, s.a, radius);
     aabb_expand_by_sphere(&s.aabb, s.b, radius);
+    return scene_push_shape(sc, &s);
+}
+int orc_scene_add_triangle(orc_scene* sc, const float p0[3], const float p1[3], const float p2[3])
+{
+    shape_t s; memset(&s, 0, sizeof s);
+    aabb_init(&s.aabb); s.has_culling_bounds = 1; s.kind = ORC_SHAPE_TRIANGLE;
+    s.a = v3(p0[0], p0[1], p0[2]); s.b = v3(p1[0], p1[1], p1[2]); s.c = v3(p2[0], p2[1], p2[2]);
+    aabb_expand(&s.aabb, s.a); aabb_expand(&s.aabb, s.b); aabb_expand(&s.aabb, s.c);
     return scene_push_shape(sc, &s);
 }
 int orc_scene_set_material(orc_scene* sc, int shape, const orc_material_node* nodes, int n)

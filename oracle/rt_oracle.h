@@ -61,10 +61,11 @@ void orc_scene_destroy(orc_scene*);
  * the one-triangle-per-leaf tree.  Returns shape index or <0. */
 int orc_scene_add_mesh_obj(orc_scene*, const char* obj_path);
 /* RSphere / RPlane / RCapsule (Src/Shapes.h:46-112, Src/Shapes.cpp:18-125, Src/RRay.cpp:25-87); shapes keep insertion order */
-enum { ORC_SHAPE_MESH = 0, ORC_SHAPE_SPHERE = 1, ORC_SHAPE_PLANE = 2, ORC_SHAPE_CAPSULE = 3 };
+enum { ORC_SHAPE_MESH = 0, ORC_SHAPE_SPHERE = 1, ORC_SHAPE_PLANE = 2, ORC_SHAPE_CAPSULE = 3, ORC_SHAPE_TRIANGLE = 4 };
 int orc_scene_add_sphere(orc_scene*, const float center[3], float radius);
 int orc_scene_add_plane(orc_scene*, const float normal[3], const float point[3]);
 int orc_scene_add_capsule(orc_scene*, const float start[3], const float end[3], float radius);
+int orc_scene_add_triangle(orc_scene*, const float p0[3], const float p1[3], const float p2[3]);   /* RTriangle (Src/Shapes.h:106-130) */
 int orc_scene_set_material(orc_scene*, int shape, const orc_material_node* nodes, int n);
 
 /* mesh introspection (for parser / topology digests) */

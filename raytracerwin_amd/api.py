@@ -229,6 +229,17 @@ class RCapsule:
         return RCapsule(InStart, InEnd, InRadius)
 
 
+class RTriangle:
+    """RTriangle::Create(p0, p1, p2) (Src/Shapes.h:106-130)"""
+
+    def __init__(self, p0, p1, p2):
+        self.Points = [tuple(float(v) for v in p) for p in (p0, p1, p2)]
+
+    @staticmethod
+    def Create(p0, p1, p2):
+        return RTriangle(p0, p1, p2)
+
+
 # ---------------------------------------------------------------------------------------------
 _live_contexts = weakref.WeakSet()
 
@@ -354,6 +365,8 @@ class RayTracerScene:
             _check(L.rtw_scene_add_sphere(self.h, v3(Shape.Center), C.c_float(Shape.Radius), C.byref(idx)))
         elif isinstance(Shape, RPlane):
             _check(L.rtw_scene_add_plane(self.h, v3(Shape.Normal), v3(Shape.Point), C.byref(idx)))
+        elif isinstance(Shape, RTriangle):
+            _check(L.rtw_scene_add_triangle(self.h, v3(Shape.Points[0]), v3(Shape.Points[1]), v3(Shape.Points[2]), C.byref(idx)))
         elif isinstance(Shape, RCapsule):
             _check(L.rtw_scene_add_capsule(self.h, v3(Shape.Start), v3(Shape.End), C.c_float(Shape.Radius), C.byref(idx)))
         elif Shape.Filename is not None:

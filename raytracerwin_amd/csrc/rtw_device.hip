@@ -786,7 +786,8 @@ __device__ __forceinline__ bool cylinder_test(const Ray& r, f3 start, f3 end, fl
     return true;
 }
 // One analytic shape against the ray.  `part` tells what wrote the result: 0 = a sphere, a plane or a capsule's side (they set
-// position, normal and distance only: the result's sampled colour and alpha stay what an earlier shape left there), 1 / 2 = the
+// position, normal and distance only: the result's sampled colour and alpha stay what an earlier shape left there; so does an
+// RTriangle), 1 / 2 = the
 // capsule's end sphere at Start / End (RCapsule::TestRayIntersection copies a fresh RayHitResult in, which resets them;
 // of two end hits the nearer, the second on a tie: Src/Shapes.cpp:34-62).
 __device__ __forceinline__ bool analytic_test(const RtwShapeDev& sh, const Ray& r, float seg, f3& pos, float& dist, int& part)
@@ -795,6 +796,9 @@ __device__ __forceinline__ bool analytic_test(const RtwShapeDev& sh, const Ray& 
     part = 0;
     if (sh.kind == RTW_SHAPE_SPHERE) return sphere_test(r, seg, a, sh.radius, pos, dist);
     if (sh.kind == RTW_SHAPE_PLANE) return plane_test(r, seg, a, b, pos, dist);
+    if (sh.kind == RTW_SHAPE_TRIANGLE)      // RTriangle::TestRayIntersection -> RRay::TestIntersectionWithTriangle (Src/Shapes.cpp:127-130)
+        return triangle_test(r, seg, make_float4(a.x, a.y, a.z, sh.pn[0]), make_float4(b.x, b.y, b.z, sh.pn[1]),
+                             make_float4(sh.pc[0], sh.pc[1], sh.pc[2], sh.pn[2]), sh.pd1, pos, dist);
     if (sh.kind != RTW_SHAPE_CAPSULE) return false;
     if (cylinder_test(r, a, b, sh.radius, pos, dist)) return true;
     f3 p1 = mk(0, 0, 0), p2 = mk(0, 0, 0); float d1 = 0.0f, d2 = 0.0f;
@@ -809,6 +813,7 @@ __device__ __forceinline__ f3 analytic_normal(const RtwShapeDev& sh, f3 pos, int
 {
     const f3 a = mk(sh.pa[0], sh.pa[1], sh.pa[2]), b = mk(sh.pb[0], sh.pb[1], sh.pb[2]);
     if (sh.kind == RTW_SHAPE_PLANE) return a;
+    if (sh.kind == RTW_SHAPE_TRIANGLE) return mk(sh.pn[0], sh.pn[1], sh.pn[2]);
     if (sh.kind == RTW_SHAPE_SPHERE || part == 1) return normalized(pos - a);
     if (part == 2) return normalized(pos - b);
     const f3 side = cross(b - a, pos - a);

@@ -28,6 +28,7 @@ struct HostMesh {
     float bmin[3], bmax[3];            // RShape::Aabb
     int kind = RTW_SHAPE_MESH;         // a sphere / plane / capsule is a shape record without arrays (Src/Shapes.h:46-112)
     float pa[3] = { 0, 0, 0 }, pb[3] = { 0, 0, 0 }, radius = 0;
+    float pc[3] = { 0, 0, 0 }, pn[3] = { 0, 0, 0 }, pd1 = 0;
     std::vector<RtwMaterialNode> material;
     // built by build_tree():
     std::vector<RtwNode> nodes;
@@ -48,6 +49,9 @@ struct HostMesh {
 std::string load_obj(const std::string& path, HostMesh& out);
 // Validate index ranges; compute bounds if `bounds6` is null.
 std::string finish_arrays(HostMesh& m, const float* bounds6);
+// Face normal and plane offset of a triangle as RRay::TestIntersectionWithTriangle computes them (Src/RRay.cpp:138-145), the
+// same operations build_tree() uses for a mesh's triangle records.
+void triangle_plane(const float p0[3], const float p1[3], const float p2[3], float n[3], float* d1);
 // KdNode::Build restated (Src/KdTree.cpp:37-126) + flatten to preorder/skip-link form.
 void build_tree(HostMesh& m);
 // 4-wide collapse of m.nodes (slot order = preorder), numbered breadth-first.

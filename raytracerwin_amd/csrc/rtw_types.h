@@ -72,6 +72,7 @@ struct RtwMaterialNode {    // mirrors rtw_material_node
 #define RTW_SHAPE_SPHERE 1
 #define RTW_SHAPE_PLANE 2
 #define RTW_SHAPE_CAPSULE 3
+#define RTW_SHAPE_TRIANGLE 4
 
 struct RtwShapeDev {
     const RtwNode* nodes;
@@ -95,9 +96,11 @@ struct RtwShapeDev {
     int32_t has_material;
     int32_t n_material_nodes;
     // RTW_SHAPE_MESH: everything above; a sphere / plane / capsule has no arrays, only these (Src/Shapes.h:46-112):
-    //   sphere: pa = Center, radius;  plane: pa = Normal, pb = Point;  capsule: pa = Start, pb = End, radius
+    //   sphere: pa = Center, radius;  plane: pa = Normal, pb = Point;  capsule: pa = Start, pb = End, radius;  triangle: see pc
     int32_t kind;
     float pa[3], pb[3], radius;
+    float pc[3], pn[3], pd1;        // triangle (RTriangle, Src/Shapes.h:106-130): pa, pb, pc = Points[0..2]; pn = its face normal and pd1 = dot(pn, pa) as
+                                    // RRay::TestIntersectionWithTriangle computes them at every test (Src/RRay.cpp:138-145), here once on the host
     int32_t pad_kind;
     RtwTexture textures[RTW_DEV_MAX_TEXTURES];
     RtwMaterialNode material[RTW_DEV_MAX_MATERIAL_NODES];

@@ -423,6 +423,25 @@ int rtw_scene_add_capsule(rtw_scene* scene, const float start[3], const float en
 {
     return add_analytic(scene, RTW_SHAPE_CAPSULE, start, end, radius, out_shape);
 }
+// RTriangle::Create(p0, p1, p2) (Src/Shapes.h:106-130): the culling box is the three points' (RAabb::Expand)
+int rtw_scene_add_triangle(rtw_scene* scene, const float p0[3], const float p1[3], const float p2[3], int* out_shape)
+{
+    if (!p2) return fail(RTW_ERR_INVALID, "null argument");
+    int idx = -1;
+    const int rc = add_analytic(scene, RTW_SHAPE_TRIANGLE, p0, p1, 0.0f, &idx);
+    if (rc != RTW_OK) return rc;
+    rtw::HostMesh& m = *scene->meshes[(size_t)idx];
+    for (int k = 0; k < 3; k++) m.pc[k] = p2[k];
+    const float* pts[3] = { m.pa, m.pb, m.pc };
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) {
+            if (pts[i][k] < m.bmin[k]) m.bmin[k] = pts[i][k];
+            if (pts[i][k] > m.bmax[k]) m.bmax[k] = pts[i][k];
+        }
+    rtw::triangle_plane(m.pa, m.pb, m.pc, m.pn, &m.pd1);
+    if (out_shape) *out_shape = idx;
+    return RTW_OK;
+}
 
 int rtw_scene_set_texture(rtw_scene* scene, int shape, int material_id, const uint8_t* texels, int width, int height, int channels)
 {
@@ -555,7 +574,8 @@ int rtw_scene_commit(rtw_scene* scene)
         d.n_material_nodes = (int)m.material.size();
         for (size_t k = 0; k < m.material.size(); k++) d.material[k] = m.material[k];
         d.kind = m.kind; d.radius = m.radius;
-        for (int k = 0; k < 3; k++) { d.pa[k] = m.pa[k]; d.pb[k] = m.pb[k]; }
+        for (int k = 0; k < 3; k++) { d.pa[k] = m.pa[k]; d.pb[k] = m.pb[k]; d.pc[k] = m.pc[k]; d.pn[k] = m.pn[k]; }
+        d.pd1 = m.pd1;
         if (m.kind != RTW_SHAPE_MESH) {
             scene->has_analytic = true;
             if (textured_mesh_before) scene->texture_carry = true;

@@ -308,6 +308,14 @@ struct TreeBuilder {
 
 }  // namespace
 
+void triangle_plane(const float p0[3], const float p1[3], const float p2[3], float n[3], float* d1)
+{
+    const Vec3 a = { p0[0], p0[1], p0[2] }, b = { p1[0], p1[1], p1[2] }, c = { p2[0], p2[1], p2[2] };
+    const Vec3 nn = normalized(cross(sub(b, a), sub(c, a)));
+    n[0] = nn.x; n[1] = nn.y; n[2] = nn.z;
+    *d1 = dot(nn, a);
+}
+
 void build_tree(HostMesh& m)
 {
     m.nodes.clear(); m.tris.clear(); m.shade.clear(); m.max_depth = 0;

@@ -156,6 +156,8 @@ def write_scene_file(scene, tmp, tag):
             lines.append("plane %s %s %s" % (num(sh[1]), num(sh[2]), mat))
         elif sh[0] == "capsule":
             lines.append("capsule %s %s %s %s" % (num(sh[1]), num(sh[2]), num(sh[3]), mat))
+        elif sh[0] == "triangle":
+            lines.append("triangle %s %s %s %s" % (num(sh[1]), num(sh[2]), num(sh[3]), mat))
         else:
             lines.append("mesh %s %s" % (obj_path(sh[1]), mat))
     path = os.path.join(tmp, tag + ".scene")
@@ -187,7 +189,7 @@ def golden_scene_frame(name, tag, W, Hh, ns, depth, preview, seed, pass0, npass,
 
 def main_scenes(tmp, rng, bounds):
     """multi-shape scenes: RSphere / RPlane / RCapsule beside meshes (tests/scenes.py)"""
-    for tag in ("default_nofuzz", "quirk", "shapes", "room"):
+    for tag in ("default_nofuzz", "quirk", "shapes", "room", "tris"):
         golden_scene_closest(tag, 700, tmp, rng, bounds)
     S = golden_scene_frame
     S("default_d5", "default", 80, 80, 4, 5, 0, 12345, 0, 1, tmp)
@@ -198,6 +200,7 @@ def main_scenes(tmp, rng, bounds):
     S("shapes_d6", "shapes", 96, 64, 4, 6, 0, 9, 1, 2, tmp)
     S("shapes_1spp_d2", "shapes", 50, 70, 1, 2, 0, 9, 0, 1, tmp)
     S("room_d8", "room", 64, 64, 4, 8, 0, 21, 0, 1, tmp)
+    S("tris_d5", "tris", 96, 96, 4, 5, 0, 4, 0, 1, tmp)
 
 
 def main():

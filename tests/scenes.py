@@ -2,6 +2,7 @@
 
 A scene is a list of shapes in insertion order:
     ("sphere", center, radius, material) | ("plane", normal, point, material) | ("capsule", start, end, radius, material)
+    | ("triangle", p0, p1, p2, material)
     | ("mesh", asset name, material)
 with material = a preorder node list for oracle.materials() / None (no material).  All numbers are float32 values."""
 import numpy as np
@@ -101,7 +102,23 @@ def room_scene():
     return d[:6] + room[:3] + [("mesh", "TorusKnot", diffuse((0.9, 0.9, 0.9)))] + room[3:] + d[6:7]
 
 
-SCENES = {"room": room_scene, "default": lambda: default_scene(True), "default_nofuzz": lambda: default_scene(False),
+def tris_scene():
+    """RTriangle shapes (Src/Shapes.h:106-130: single-sided, face normal, culled by their own box -- an axis-aligned one has a
+    zero-thickness box the reference's slab test never passes for a ray with a component on that axis, so it is invisible),
+    with a sphere, the ground and a textured mesh before one of them (its hits inherit the mesh's texel)."""
+    return [
+        ("triangle", (-2.5, -1.0, -1.0), (0.5, -1.2, 0.5), (-1.0, 2.0, -0.5), blend(reflective((0.9, 0.9, 0.9)), diffuse((0.9, 0.4, 0.2)), 0.5)),
+        ("triangle", (0.5, -1.0, 1.0), (2.5, -1.0, 1.0), (1.5, 1.5, 1.0), diffuse((0.2, 0.9, 0.3))),        # z = 1 plane: invisible
+        ("mesh", "unitychan", diffuse((1, 1, 1))),
+        ("triangle", (-0.8, -0.5, 1.5), (0.8, -0.6, 1.2), (0.1, 1.0, 1.6), diffuse((0.8, 0.8, 1.0))),       # in front of the mesh
+        ("triangle", (0.8, -0.5, 1.5), (-0.8, -0.6, 1.2), (0.1, 1.0, 1.6), diffuse((1.0, 0.2, 0.2))),       # wound away from the camera
+        ("sphere", (1.8, 0.0, 0.0), 0.7, reflective((0.9, 0.9, 0.9))),
+        ("plane", (0.0, 1.0, 0.0), (0.0, -2.0, 0.0), checker((0.9, 0.9, 0.9), 2.0)),
+        ("triangle", (2.0, 1.0, 0.0), (2.0, 1.0, 0.0), (3.0, 2.0, 0.0), diffuse((1, 1, 1))),                # degenerate
+    ]
+
+
+SCENES = {"tris": tris_scene, "room": room_scene, "default": lambda: default_scene(True), "default_nofuzz": lambda: default_scene(False),
           "quirk": quirk_scene, "shapes": shapes_scene}
 
 
@@ -114,6 +131,9 @@ def scene_bounds(scene, mesh_bounds):
         elif s[0] == "capsule":
             for c in (s[1], s[2]):
                 lo = np.minimum(lo, np.array(c) - s[3]); hi = np.maximum(hi, np.array(c) + s[3])
+        elif s[0] == "triangle":
+            for c in s[1:4]:
+                lo = np.minimum(lo, np.array(c)); hi = np.maximum(hi, np.array(c))
         elif s[0] == "mesh":
             b = mesh_bounds[s[1]]
             lo = np.minimum(lo, b[:3]); hi = np.maximum(hi, b[3:])

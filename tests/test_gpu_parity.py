@@ -438,6 +438,8 @@ def multi_scene_gpu(ctx, tag):
             s.AddShape(R.RPlane.Create(sh[1], sh[2]), mat)
         elif sh[0] == "capsule":
             s.AddShape(R.RCapsule.Create(sh[1], sh[2], sh[3]), mat)
+        elif sh[0] == "triangle":
+            s.AddShape(R.RTriangle.Create(sh[1], sh[2], sh[3]), mat)
         else:
             s.AddShape(R.RMeshShape.Create(asset(sh[1] + ".obj")), mat)
     s.commit()
@@ -445,7 +447,7 @@ def multi_scene_gpu(ctx, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["default_nofuzz", "quirk", "shapes", "room"])
+@pytest.mark.parametrize("tag", ["default_nofuzz", "quirk", "shapes", "room", "tris"])
 def test_scene_closest_hit_vs_reference_golden(ctx, tag):
     """FindIntersectionWithScene over spheres, planes, capsules and meshes in insertion order, bit-exact against the reference's
     own outputs -- including (scene "quirk") the sampled colour an analytic hit inherits from an earlier textured-mesh hit."""
@@ -458,7 +460,7 @@ def test_scene_closest_hit_vs_reference_golden(ctx, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["default_nofuzz_d5", "default_preview", "quirk_d4", "quirk_preview", "shapes_d6", "shapes_1spp_d2", "room_d8"])
+@pytest.mark.parametrize("name", ["default_nofuzz_d5", "default_preview", "quirk_d4", "quirk_preview", "shapes_d6", "shapes_1spp_d2", "room_d8", "tris_d5"])
 @pytest.mark.parametrize("pipeline", [3, 0])
 def test_scene_frame_vs_reference_golden(ctx, name, pipeline):
     """RayTracerProgram::SetupScene's scene (fuzziness zeroed, see tests/scenes.py), the texture-inheritance scene and the
@@ -498,7 +500,7 @@ def test_default_scene_with_fuzz_vs_oracle_f64_mode_and_close_to_reference(ctx, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,W,H,ns,depth", [("default", 1280, 720, 4, 5), ("shapes", 800, 800, 4, 6), ("default_nofuzz", 333, 211, 3, 4),
-                                              ("quirk", 640, 360, 4, 4), ("room", 800, 800, 4, 8)])
+                                              ("quirk", 640, 360, 4, 4), ("room", 800, 800, 4, 8), ("tris", 512, 512, 4, 5)])
 def test_scene_pipelines_agree_at_size(ctx, tag, W, H, ns, depth):
     """larger frames than the oracle-sized fixtures: bins + wave pipeline == single kernel, whole frame and dealt as tasks over 3 ranks"""
     s = multi_scene_gpu(ctx, tag)

@@ -144,7 +144,7 @@ def multi_scene(O, tag):
     return _multi[tag]
 
 
-@pytest.mark.parametrize("tag", ["default_nofuzz", "quirk", "shapes", "room"])
+@pytest.mark.parametrize("tag", ["default_nofuzz", "quirk", "shapes", "room", "tris"])
 def test_scene_closest_hit_matches_reference(oracle_mod, tag):
     """FindIntersectionWithScene over spheres, planes, capsules and meshes in insertion order (Src/RayTracerScene.cpp:99-125),
     including the sampled colour a nearer analytic hit inherits from an earlier textured-mesh hit."""
@@ -162,7 +162,7 @@ def test_scene_closest_hit_matches_reference(oracle_mod, tag):
 
 
 @pytest.mark.parametrize("name", ["default_d5", "default_nofuzz_d5", "default_preview", "quirk_d4", "quirk_preview", "shapes_d6",
-                                  "shapes_1spp_d2", "room_d8"])
+                                  "shapes_1spp_d2", "room_d8", "tris_d5"])
 def test_scene_frame_matches_reference(oracle_mod, name):
     """RayTracerProgram::SetupScene's scene (Src/RayTracerProgram.cpp:467-552) and two synthetic multi-shape scenes, rendered by
     the reference's RayTrace through the harness: the oracle gives the same accumulator and ARGB bits."""

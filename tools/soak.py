@@ -39,8 +39,10 @@ def soup(rng, kind):
 
 
 def analytic(rng):
-    k = int(rng.integers(0, 3))
+    k = int(rng.integers(0, 4))
     v = lambda lo, hi: tuple(float(x) for x in rng.uniform(lo, hi, 3))  # noqa: E731
+    if k == 3:
+        return R.RTriangle.Create(v(-3, 3), v(-3, 3), v(-3, 3))
     if k == 0:
         return R.RSphere.Create(v(-3, 3), float(rng.choice([0.05, 0.5, 1.5, 8.0])))       # 8.0: the camera may sit inside
     if k == 1:
