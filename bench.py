@@ -256,8 +256,10 @@ def main():
 
     from raytracerwin_amd import sharding
 
-    def step(i):
-        scene.render_tasks(fb, TASK_ROWS, rank, world, depth, None, i, spp, SEED)
+    def steps(first, n):
+        # n steps = n passes of the reference's sample loop (UpdateBitmapPixels, Src/RayTracerProgram.cpp:317-361) over this rank's
+        # 10-row tasks: one rtw_render_passes call, pass indices first .. first + n - 1
+        scene.render_passes(fb, TASK_ROWS, rank, world, depth, None, first, n, spp, SEED)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -267,8 +269,7 @@ def main():
 
     K, Wm = args.steps, args.warmup
     with torch.cuda.stream(stream):
-        for i in range(Wm):
-            step(i)
+        steps(0, Wm)
     barrier()
     accum.zero_()
     argb.zero_()
@@ -279,8 +280,7 @@ def main():
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
-        for i in range(K):
-            step(i)
+        steps(0, K)
         ev1.record(stream)
         if world > 1:
             # the one exchange of the path: every rank's rows of (accumulator, ARGB) to rank 0 over RCCL

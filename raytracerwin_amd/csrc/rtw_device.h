@@ -36,6 +36,11 @@ struct PipelineTuning {
     // between the two events (fork after the previous work of the main stream, join before the pass ends); aux_stream null = one kernel
     hipStream_t aux_stream; hipEvent_t fork_event, join_event; int sky_job0; const float* gamma_thr;
     bool has_analytic = false;  // some shape is a sphere / plane / capsule: the kernels' instantiations that hold those tests are launched
+    // a run of passes inside one rtw_render_passes call forks the second stream before its first pass and joins it after its last:
+    // between those passes nothing else can be enqueued, the sky kernels are ordered on their own stream and write pixels no other
+    // kernel of the run writes
+    bool do_fork = true, do_join = true;
+    bool* aux_unjoined = nullptr;   // set when a sky kernel was launched and the join was left to a later pass
     bool skip_trace = false;    // every shape is a leading analytic shape: the shading lanes do the whole scene query, no trace launches
     bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
     int trace_block;       // threads per block of the unstaged trace kernel: 256 (default), 128 or 64

@@ -1380,6 +1380,8 @@ struct PipeBufs {
     uint32_t* __restrict__ tlist0;     // trace lists (slots whose next segment must be traced), ping-pong
     uint32_t* __restrict__ tlist1;
     uint32_t capacity;                 // slots the dense arrays hold
+    float4* __restrict__ accum;        // the framebuffer (RtwRenderParams::resolve_inline: a path's last shading step resolves its pixel)
+    uint32_t* __restrict__ argb;
 };
 
 // like wave_push, returns the index the value was stored at (or 0xFFFFFFFF)
@@ -1608,6 +1610,29 @@ __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32
     }
 }
 
+// End of the pass's last kernel (whole blocks call it after their work).  The last block to finish files the counters for the host
+// (queue lengths, sizes of the next launches), zeroes them for the next pass (which saves that pass a memset launch) and advances the
+// pass index of a replayed launch graph.  Every block has read what it needs of both before it takes its ticket.
+__device__ __forceinline__ void pass_epilogue(const PipeBufs& pb, const RtwRenderParams& p)
+{
+#ifndef RTW_HOST_EMUL
+    if (p.self_clean) {
+        __shared__ uint32_t last_block;
+        __syncthreads();
+        if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (last_block && threadIdx.x < 64) {
+            const uint32_t v = threadIdx.x == 40 ? 0u : pb.counters[threadIdx.x];
+            pb.counters[64 + threadIdx.x] = v;
+            pb.counters[threadIdx.x] = 0u;
+        }
+        if (last_block && threadIdx.x == 0 && p.pass_ptr) *p.pass_ptr += 1;        // every other block is done with the pass index
+    } else if (p.pass_ptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        *p.pass_ptr += 1;           // (resolve_kernel only: nothing in it reads the pass index)
+    }
+#endif
+}
+
 // RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94) for one path whose segment has just been traced: shade the
 // recorded hit (r0 = position + distance, r1 = shape + leaf slot; shape < 0 = the segment missed), push a level, set up
 // the next segment; or finish the path (fold the levels back in the reference's association order, write the radiance).
@@ -1615,7 +1640,8 @@ __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32
 // state is then saved in slot q.
 template <bool STATS, bool AN>
 __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ sc, const PipeBufs& pb, const RtwRenderParams& p, uint32_t q, uint32_t pid,
-                                               Ray ray, PathRng rng, int depth, int nlev, bool have_hit, float4 r0, float4 r1, Counters& ct)
+                                               Ray ray, PathRng rng, int depth, int nlev, bool have_hit, float4 r0, float4 r1, Counters& ct,
+                                               const float* __restrict__ thr)      // the block's gamma staircase in LDS (used with resolve_inline)
 {
     TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
     if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
@@ -1667,6 +1693,10 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
                 L = mk(0, 0, 0) + L;
             }
         }
+        if (p.resolve_inline) {     // the pixel's only sample: c = (0 + s[0]) / 1, then AccumulatePixel::AddPixel + GetGammaSpacePixel
+            resolve_pixel(thr, pb.accum, pb.argb, work_to_pixel(p, (int)(pid >> 2)), mk(0, 0, 0) + L, p.preview != 0);
+            return false;
+        }
         pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
         return false;
     }
@@ -1704,8 +1734,10 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
 }
 
 template <bool STATS, bool AN>
-__global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
+__global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int last)
 {
+    __shared__ float thr[256];
+    if (p.resolve_inline) { thr[threadIdx.x] = sc->gamma_thr[threadIdx.x]; __syncthreads(); }
     // the round's input list: round 0 = the path queue itself; with direct slots the queue is round 0's TRACE list (round 1's input)
     const bool from_queue = p.direct_slots && round == 1;
     const uint32_t n = (round == 0 || from_queue) ? pb.counters[0] : pb.counters[4 + round - 1];
@@ -1746,11 +1778,12 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
                 const size_t rec = (round == 0 && p.wavefront == 2) ? (size_t)pid : (size_t)q;
                 r0 = pb.hitslot[rec * 2]; r1 = pb.hitslot[rec * 2 + 1];
             }
-            go_on = shade_hit_step<STATS, AN>(sc, pb, p, q, pid, ray, rng, depth, nlev, have_hit, r0, r1, ct);
+            go_on = shade_hit_step<STATS, AN>(sc, pb, p, q, pid, ray, rng, depth, nlev, have_hit, r0, r1, ct, thr);
         }
         wave_push(dst, &pb.counters[4 + round], go_on, q);
     }
     if (STATS) flush_counters(sc, ct);
+    if (last) pass_epilogue(pb, p);     // resolve_inline: this is the pass's last launch
 }
 
 #ifndef RTW_HOST_EMUL
@@ -1828,21 +1861,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restr
         c = c / (float)p.sub_samples;
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
     }
-    if (p.pass_ptr && blockIdx.x == 0 && threadIdx.x == 0) *p.pass_ptr += 1;       // last kernel of the pass; nothing here reads the pass index
-    if (p.self_clean) {
-        // Last kernel of the pass: the last block to finish files the counters for the host (queue lengths, sizes of the next
-        // launches) and zeroes them for the next pass, which saves that pass a memset launch.  Every block has read the one
-        // counter it needs (n, above) before it takes its ticket.
-        __shared__ uint32_t last_block;
-        __syncthreads();
-        if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == gridDim.x - 1u ? 1u : 0u;
-        __syncthreads();
-        if (last_block && threadIdx.x < 64) {
-            const uint32_t v = threadIdx.x == 40 ? 0u : pb.counters[threadIdx.x];
-            pb.counters[64 + threadIdx.x] = v;
-            pb.counters[threadIdx.x] = 0u;
-        }
-    }
+    pass_epilogue(pb, p);
 }
 
 template <bool STATS>
@@ -1955,6 +1974,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     if (!tune.counters_clean) e = hipMemsetAsync(pb.counters, 0, 256, stream);     // else: the previous pass's resolve_kernel left them zeroed
     if (e != hipSuccess) return (int)e;
     pb.hitslot = pb.hitrec; pb.state = nullptr; pb.tlist0 = pb.tlist1 = nullptr; pb.capacity = 0;
+    pb.accum = (float4*)accum; pb.argb = (uint32_t*)argb;
     if (p.wavefront) {
         pb.state = (float4*)(w + l.wf_state_off); pb.tlist0 = (uint32_t*)(w + l.wf_tlist0_off); pb.tlist1 = (uint32_t*)(w + l.wf_tlist1_off);
         pb.ws = (float4*)(w + l.wf_ws_off); pb.capacity = (uint32_t)l.wf_capacity;
@@ -1980,13 +2000,14 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         RtwRenderParams ph = p;
         if (tune.aux_stream && p.tile_order && tune.sky_job0 > 0 && tune.sky_job0 < p.n_jobs && !stats) {
             // sky-only tiles on the second stream, beside everything else of this pass
-            forked = hipEventRecord(tune.fork_event, stream) == hipSuccess && hipStreamWaitEvent(tune.aux_stream, tune.fork_event, 0) == hipSuccess;
+            forked = !tune.do_fork || (hipEventRecord(tune.fork_event, stream) == hipSuccess && hipStreamWaitEvent(tune.aux_stream, tune.fork_event, 0) == hipSuccess);
             if (forked) {
                 const int sky_jobs = p.n_jobs - tune.sky_job0;
                 int sgrid = (sky_jobs + 3) / 4;
                 if (sgrid > tune.wave_blocks * tune.primary_blocks_per_cu) sgrid = tune.wave_blocks * tune.primary_blocks_per_cu;
                 hipLaunchKernelGGL(primary_sky_kernel, dim3(sgrid), dim3(block), 0, tune.aux_stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, p, tune.sky_job0);
-                (void)hipEventRecord(tune.join_event, tune.aux_stream);
+                if (tune.do_join) (void)hipEventRecord(tune.join_event, tune.aux_stream);
+                else if (tune.aux_unjoined) *tune.aux_unjoined = true;
                 ph.n_jobs = tune.sky_job0;
             }
         }
@@ -2082,12 +2103,13 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
             long long sb = (items_of(r) + 255) / 256;
             if (sb < 1) sb = 1;
             if (sb > 262144) sb = 262144;
+            const int last = (p.resolve_inline && r == p.max_bounce - 1) ? 1 : 0;     // no resolve launch follows: this one closes the pass
             if (tune.has_analytic) {
-                if (stats) hipLaunchKernelGGL((shade_kernel<true, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
-                else hipLaunchKernelGGL((shade_kernel<false, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+                if (stats) hipLaunchKernelGGL((shade_kernel<true, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
+                else hipLaunchKernelGGL((shade_kernel<false, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
             } else {
-                if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
-                else hipLaunchKernelGGL((shade_kernel<false, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+                if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
+                else hipLaunchKernelGGL((shade_kernel<false, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
             }
         }
     } else if (p.wavefront == 2) {
@@ -2135,8 +2157,8 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                 else hipLaunchKernelGGL(trace_kernel<false>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
             }
             const int sb = size_for(r, 1);
-            if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r);      // (scenes with analytic shapes never take this pipeline)
-            else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r);
+            if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r, 0);      // (scenes with analytic shapes never take this pipeline)
+            else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r, 0);
         }
     } else if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
         constexpr int NT = 256;         // experiment: no register cap (2 waves/SIMD), staged tree per 4 waves
@@ -2186,8 +2208,11 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
         else hipLaunchKernelGGL((path_kernel<false, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
-    hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-    if (forked) (void)hipStreamWaitEvent(stream, tune.join_event, 0);      // the pass is complete when both streams are
+    if (!p.resolve_inline) hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    if (forked && tune.do_join) {           // the pass (or the run of passes) is complete when both streams are
+        (void)hipStreamWaitEvent(stream, tune.join_event, 0);
+        if (tune.aux_unjoined) *tune.aux_unjoined = false;
+    }
     if (tune.timing) (void)hipEventRecord(tune.timing[3], stream);
     return (int)hipGetLastError();
 }

@@ -139,6 +139,10 @@ struct RtwRenderParams {
                                     // leaves the partial scene query in the path's hit record; the wave-per-ray trace continues from it
     int32_t self_clean;             // resolve_kernel files the counters at word 64.. and zeroes them for the next pass
     int32_t n_jobs;                 // entries of tile_order
+    int32_t resolve_inline;         // bins + wave pipeline, ONE sample per pixel: the lane that ends a path accumulates and resolves its pixel
+                                    // there and then (no pending list, no resolve launch; the pass's last shade launch does the end-of-pass
+                                    // bookkeeping); with several samples a pixel waits for all of them and resolve_kernel sums them in order
+    int32_t pad_resolve;
     const struct RtwBinsDev* bins;  // [n_shapes] or null
     int32_t* pass_ptr;              // not null: the pass index lives on the device (replayed launch graphs); resolve_kernel adds 1 to it
     const uint32_t* tile_order;     // full-frame launches: the order in which the primary kernel takes the tiles (null = as numbered)

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         if (live && (near_wave || only_sample >= 0) && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
         if (queue_it && p.direct_slots) {                    // shade the hit here: the path's slot needs no queue position
             hit_any = true;
-            if (shade_hit_step<STATS, AN>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, true, hr0, hr1, ct))
+            if (shade_hit_step<STATS, AN>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, true, hr0, hr1, ct, thr))
                 queued |= 1u << i;                           // it goes on: its slot joins round 0's trace list below
         } else if (queue_it) {                               // the hit record waits under the path id; the queue entry follows below
             hit_any = true;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     // the pending list one per pixel with a queued sample
     // a tile split by sub-sample: every pixel is pending (listed once, by the wave of sub-sample 0)
     const bool pending = only_sample >= 0 ? live : hit_any;
-    const bool list_pixel = only_sample >= 0 ? (live && only_sample == 0) : pending;
+    const bool list_pixel = p.resolve_inline ? false : (only_sample >= 0 ? (live && only_sample == 0) : pending);      // resolve_inline: whoever ends the pixel's one path resolves it
     {
         const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
                                  m3 = __ballot((queued & 8u) != 0u), mp = __ballot(list_pixel);

@@ -61,6 +61,10 @@ struct rtw_context {
     bool own_stream = false;
     hipStream_t aux_stream = nullptr;   // sky-only tiles of the bins + wave pipeline run here, beside the main stream
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    int batch_pos = 0;                  // rtw_render_passes: 0 = a pass on its own, 1 = first of a run, 2 = inside a run, 3 = last of a run
+    bool aux_unjoined = false;          // a sky kernel of the current run is not joined yet
+    int batch_passes = 1;               // 0: every pass forks and joins the second stream by itself (for comparison)
+    int resolve_inline = 1;             // pipeline 3, one sample per pixel: a path's last shading step resolves its pixel (0: the resolve kernel does)
     int lead_split = 1;                 // pipeline 3: leading analytic shapes are tested by the shading lanes (0: by the trace waves, for comparison)
     int direct_slots = 1;               // pipeline 3: the primary kernel shades the camera rays' hits itself (no shade(0) launch, no queue)
     int sky_split = 1;                  // 0 = one primary kernel for every tile
@@ -260,6 +264,8 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "batch_passes") == 0) { ctx->batch_passes = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "resolve_inline") == 0) { ctx->resolve_inline = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "lead_split") == 0) { ctx->lead_split = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "sky_split") == 0) { ctx->sky_split = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "use_graph") == 0) { ctx->use_graph = value ? 1 : 0; return RTW_OK; }
@@ -997,6 +1003,8 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
         tune.aux_stream = (cx->sky_split && !capturing) ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
         tune.sky_job0 = sky_job0; tune.gamma_thr = cx->d_gamma;
+        tune.do_fork = cx->batch_pos == 0 || cx->batch_pos == 1 || !cx->aux_unjoined;      // (a run whose earlier passes launched no sky kernel has not forked yet)
+        tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
         tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.trace_block = cx->trace_block; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
@@ -1027,6 +1035,8 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         const size_t coff = rtw::pipeline_counters_offset(p.count, max_bounce);
         p.self_clean = p.wavefront == 2 ? 1 : 0;
         p.direct_slots = (p.wavefront == 2 && cx->direct_slots && !cx->wave_fused && !cx->wave_tail) ? 1 : 0;
+        // one sample per pixel: the lane that ends a path resolves its pixel (no pending list, no resolve launch)
+        p.resolve_inline = (p.direct_slots && cx->resolve_inline && sub_samples == 1 && max_bounce >= 2) ? 1 : 0;
         {   // leading spheres / planes / capsules are tested by the lane that sets a segment up (see RtwRenderParams::lead_shapes)
             int lead = 0;
             while (lead < (int)scene->meshes.size() && scene->meshes[(size_t)lead]->kind != RTW_SHAPE_MESH) lead++;
@@ -1113,7 +1123,16 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
             g.next_pass = pass + 1;
             continue;
         }
+        // passes launched kernel by kernel inside this call form a run: the second stream is forked before the first and joined after the last
+        const bool run = cx->batch_passes && !cx->use_graph && n_passes > 1;
+        cx->batch_pos = !run ? 0 : (i + 1 == n_passes ? 3 : (i == 0 ? 1 : 2));
         rc = rtw_render_tasks(scene, fb, task_rows, rank, world, max_bounce, use_base_color, pass, sub_samples, seed);
+        cx->batch_pos = 0;
+        if (cx->aux_unjoined && (rc != RTW_OK || i + 1 == n_passes)) {      // the run ends here (an error, or a last pass that launched no sky kernel)
+            (void)hipEventRecord(cx->join_event, cx->aux_stream);
+            (void)hipStreamWaitEvent(cx->stream, cx->join_event, 0);
+            cx->aux_unjoined = false;
+        }
         if (rc != RTW_OK) return rc;
         if (!cx->use_graph || cx->stats_enabled || cx->kernel_timing || cx->pipeline != 3 || i + 1 >= n_passes) continue;
         // wait for this pass's queue lengths, then capture the next pass

@@ -514,3 +514,49 @@ def test_scene_pipelines_agree_at_size(ctx, tag, W, H, ns, depth):
         for rank in range(3):
             s.render_tasks(fb, 10, rank, 3, depth, None, p, ns, 31)
     assert (bits(fb.read_float()) == bits(a3)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,W,H,depth,preview", [("TorusKnot", 1920, 1080, 4, 0), ("unitychan", 640, 360, 2, 0), ("BlenderMonkey", 800, 800, 9, 0),
+                                                    ("TorusKnot", 320, 180, 3, 1)])
+def test_single_sample_passes_resolved_by_the_shading_lanes_equal_the_resolve_kernel(ctx, mesh, W, H, depth, preview):
+    """With one sample per pixel the lane that ends a path accumulates and resolves its pixel itself and the pass has no resolve
+    launch (option resolve_inline, default on): same accumulator and ARGB bits as with the resolve kernel, over accumulated passes,
+    dealt tasks and graph replay."""
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5))
+    out = []
+    for inline in (0, 1):
+        ctx.set_option("resolve_inline", inline)
+        a, b = render_frame(ctx, s, W, H, 1, depth, preview, 2468, 2, 3)
+        fb = R.Framebuffer(ctx, W, H)
+        for rank in range(2):
+            s.render_passes(fb, 10, rank, 2, depth, R.RenderOption(bool(preview)), 2, 3, 1, 2468)
+        out.append((a, b, fb.read_float(), fb.resolve_argb()))
+    ctx.set_option("resolve_inline", 1)
+    for k in range(4):
+        assert (bits(out[0][k]) == bits(out[1][k])).all(), k
+    assert (bits(out[1][0]) == bits(out[1][2])).all() and (out[1][1] == out[1][3]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,ns,depth,world", [("TorusKnot", 1, 4, 1), ("unitychan", 4, 3, 2), ("BlenderMonkey", 2, 5, 3)])
+def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, mesh, ns, depth, world):
+    """rtw_render_passes launches its passes as one run (the second stream, which renders the sky-only tiles, is forked before the
+    first pass and joined after the last; option batch_passes): same bits as one rtw_render_tasks call per pass, also when other
+    work follows the call at once (a read-back, another rank's run into the same buffer)."""
+    W, H = 1280, 720
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.8, 1.0)))
+    ref = R.Framebuffer(ctx, W, H)
+    for rank in range(world):
+        for p in range(7):
+            s.render_tasks(ref, 10, rank, world, depth, None, p, ns, 99)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    for batch in (1, 0):
+        ctx.set_option("batch_passes", batch)
+        fb = R.Framebuffer(ctx, W, H)
+        for rank in range(world):
+            s.render_passes(fb, 10, rank, world, depth, None, 0, 4, ns, 99)
+            s.render_passes(fb, 10, rank, world, depth, None, 4, 3, ns, 99)
+        a, b = fb.read_float(), fb.resolve_argb()
+        assert (bits(a) == bits(ra)).all() and (b == rb).all(), batch
+    ctx.set_option("batch_passes", 1)
