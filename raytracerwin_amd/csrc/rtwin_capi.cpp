@@ -104,7 +104,7 @@ struct rtw_context {
     } pass_graph;
     int32_t* d_pass = nullptr;          // the replayed graph's pass index
     int32_t* h_pass = nullptr;          // pinned staging word for d_pass
-    int hint_period = 1;                // the queue lengths are read back every hint_period-th pass
+    int hint_period = 16;               // the queue lengths are read back every hint_period-th pass (a 256-byte copy costs the stream ~10 us; the lengths drift slowly)
     int hint_tick = 0;
     int use_graph = 0;                  // rtw_render_passes: 1 = replay a captured pass as a launch graph (measured: no faster, the passes are GPU-bound,
                                         // and a captured pass cannot use the second stream), 0 = launch every pass kernel by kernel
