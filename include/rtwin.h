@@ -92,7 +92,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   in their own kernel; "wave_stage" (0) LDS staging of shape 0 in the trace kernels, 1..3 = levels /
  *                   leaves / triangles, -1 = as much as fits; "wave_fused" (0) one kernel carries the paths through all
  *                   bounces; "wave_tail" (0) one kernel after the first trace round; "wave_paths", "wave_blocks_mul",
- *                   "primary_blocks_per_cu": launch geometry; "use_graph" (0) rtw_render_passes replays a launch graph.
+ *                   "primary_blocks_per_cu": launch geometry; "use_graph" (0) rtw_render_passes replays a launch graph;
+ *                   "hint_period" (16) the queue lengths that size the next launches are read back every n-th pass.
  *   pipelines 1, 2: "packets" (1) camera rays traced as 64-ray packets inside the primary kernel; "path_lanes" lanes per
  *                   ray in the path kernel: 16 (default), 4 or 1; "path_variant": occupancy variants of the path kernel.
  *   "kernel_timing" 1 = record events around the stages of each pass (rtw_last_pass_kernel_ms);
