@@ -41,6 +41,7 @@ struct PipelineTuning {
     // kernel of the run writes
     bool do_fork = true, do_join = true;
     bool* aux_unjoined = nullptr;   // set when a sky kernel was launched and the join was left to a later pass
+    bool finish_in_trace = false;   // the last trace round finishes its paths itself (see trace_wave_kernel FINISH): no last shade launch
     bool skip_trace = false;    // every shape is a leading analytic shape: the shading lanes do the whole scene query, no trace launches
     bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
     int trace_block;       // threads per block of the unstaged trace kernel: 256 (default), 128 or 64

@@ -1613,13 +1613,13 @@ __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32
 // End of the pass's last kernel (whole blocks call it after their work).  The last block to finish files the counters for the host
 // (queue lengths, sizes of the next launches), zeroes them for the next pass (which saves that pass a memset launch) and advances the
 // pass index of a replayed launch graph.  Every block has read what it needs of both before it takes its ticket.
-__device__ __forceinline__ void pass_epilogue(const PipeBufs& pb, const RtwRenderParams& p)
+__device__ __forceinline__ void pass_epilogue(const PipeBufs& pb, const RtwRenderParams& p, uint32_t n_blocks)      // n_blocks: the blocks that call this
 {
 #ifndef RTW_HOST_EMUL
     if (p.self_clean) {
         __shared__ uint32_t last_block;
         __syncthreads();
-        if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == gridDim.x - 1u ? 1u : 0u;
+        if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == n_blocks - 1u ? 1u : 0u;
         __syncthreads();
         if (last_block && threadIdx.x < 64) {
             const uint32_t v = threadIdx.x == 40 ? 0u : pb.counters[threadIdx.x];
@@ -1783,7 +1783,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restric
         wave_push(dst, &pb.counters[4 + round], go_on, q);
     }
     if (STATS) flush_counters(sc, ct);
-    if (last) pass_epilogue(pb, p);     // resolve_inline: this is the pass's last launch
+    if (last) pass_epilogue(pb, p, gridDim.x);     // resolve_inline: this is the pass's last launch
 }
 
 #ifndef RTW_HOST_EMUL
@@ -1861,7 +1861,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restr
         c = c / (float)p.sub_samples;
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
     }
-    pass_epilogue(pb, p);
+    pass_epilogue(pb, p, gridDim.x);
 }
 
 template <bool STATS>
@@ -2052,6 +2052,16 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                     else { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<false, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
                         hipLaunchKernelGGL((trace_wave_kernel<false, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
                 } while (0)
+                if (tune.finish_in_trace && r == p.max_bounce - 1) {      // the last round: the trace waves finish their paths, no shade launch follows
+                    constexpr int NTV = 1024;   // big blocks: the blocks that had rays take a ticket each at the end (pass_epilogue), so there should be few
+                    long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);
+                    const long long cap = (long long)tune.wave_blocks * tune.wave_blocks_mul;
+                    if (blocks < 1) blocks = 1;
+                    if (blocks > cap) blocks = cap;
+                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
+                    hipLaunchKernelGGL((trace_wave_kernel<false, 0, NTV, false, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, p.resolve_inline ? 1 : 0);
+                    break;
+                }
                 if (p.lead_shapes > 0) {        // leading analytic shapes: the records are half done, most rays need no trace (see trace_wave_lead_kernel)
                     constexpr int NTV = 128;
                     int shift = 0;

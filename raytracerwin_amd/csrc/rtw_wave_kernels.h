@@ -537,13 +537,24 @@ __device__ __forceinline__ FlatSrc stage_shape0(const RtwSceneDev* __restrict__ 
 // ---- one round of secondary segments: a wave per ray -----------------------------------------------------------------
 // The wavefront pipeline's trace step (see trace_kernel) with the whole wave on one ray: the ray comes in through scalar
 // loads, the walk is wave_walk_flat on the arrays the block staged in LDS.  Persistent blocks, one per CU when staged.
-template <bool STATS, int STAGE, int NT, bool AN = false>
-__global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
+// FINISH (the pass's last trace round, scenes without an Emissive material, no preview): what the last shade step would make of
+// the result needs neither the hit's shading inputs nor its material -- a path whose last segment misses gets the sky colour, one
+// whose last segment hits gets exactly 0 (RayTrace(.., 0) is black and nothing emits: Src/RayTracerScene.cpp:39,74-77; all material
+// colours are finite, so Att * 0 is 0) -- so lane 0 folds the path's levels right here, in the order shade_hit_step does, and the
+// pass has no last shade launch.  `closes_pass`: with resolve_inline this is then the pass's last launch.
+template <bool STATS, int STAGE, int NT, bool AN = false, bool FINISH = false>
+__global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round,
+                                                                                              int closes_pass = 0)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
+    __shared__ float thr[FINISH ? 256 : 1];
+    if (FINISH && p.resolve_inline) { for (int i = (int)threadIdx.x; i < 256; i += NT) thr[FINISH ? i : 0] = sc->gamma_thr[i]; __syncthreads(); }
     const bool from_queue = p.direct_slots && round == 0;       // with direct slots the path queue IS round 0's trace list
     const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round];
-    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;         // (whole block) no ray left for this block's first wave
+    // (whole block) no ray for this block's first wave; a FINISH launch that closes the pass always keeps block 0 (someone must file the counters)
+    const uint32_t busy_blocks = (n + (uint32_t)(NT / 64) - 1u) / (uint32_t)(NT / 64);
+    const uint32_t live_blocks = busy_blocks < gridDim.x ? (busy_blocks > 0u ? busy_blocks : 1u) : gridDim.x;
+    if ((uint32_t)blockIdx.x >= live_blocks) return;
     uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
     const FlatSrc staged = stage_shape0<STAGE, NT>(sc, wave_dyn);
     const uint32_t* __restrict__ src = from_queue ? pb.queue : wf_list(pb, round & 1);
@@ -558,12 +569,31 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trac
         Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
         wave_find_intersection<STATS, STAGE, AN>(sc, 0, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
-        if (lane_id() == 0) {
+        if (FINISH) {
+            if (lane_id() == 0) {
+                const int nlev = (int)(__float_as_uint(cld4(pb.state, q * 3 + 2).z) & 0xFFFFu);
+                LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
+                f3 L = hs < 0 ? sky_color(ray.d.y) : mk(0, 0, 0);
+                for (int kk = nlev - 1; kk >= 0; kk--) {
+                    const float4 a = lv.at(kk, 0);
+                    if (__float_as_int(a.w) == 0) {
+                        const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
+                        L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
+                    } else {
+                        L = mk(0, 0, 0) + L;
+                    }
+                }
+                const uint32_t pid = pid_of_slot(p, (uint32_t)q) & 0x7FFFFFFFu;
+                if (p.resolve_inline) resolve_pixel(thr, pb.accum, pb.argb, work_to_pixel(p, (int)(pid >> 2)), mk(0, 0, 0) + L, false);
+                else pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+            }
+        } else if (lane_id() == 0) {
             pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
         }
     }
     if (STATS) flush_counters(sc, ct);
+    if (FINISH && closes_pass) pass_epilogue(pb, p, live_blocks);
 }
 
 // The trace step of a scene whose leading shapes are analytic (RtwRenderParams::lead_shapes > 0).  The lane that set a segment up

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -64,6 +65,8 @@ struct rtw_context {
     int batch_pos = 0;                  // rtw_render_passes: 0 = a pass on its own, 1 = first of a run, 2 = inside a run, 3 = last of a run
     bool aux_unjoined = false;          // a sky kernel of the current run is not joined yet
     int batch_passes = 1;               // 0: every pass forks and joins the second stream by itself (for comparison)
+    int finish_in_trace = 0;            // pipeline 3: 1 = the last trace round folds its paths' levels itself when no material emits (measured slower: the fold
+                                        // is one lane's dependent loads per ray in a wave-per-ray loop; a shade launch does it a path per lane)
     int resolve_inline = 1;             // pipeline 3, one sample per pixel: a path's last shading step resolves its pixel (0: the resolve kernel does)
     int lead_split = 1;                 // pipeline 3: leading analytic shapes are tested by the shading lanes (0: by the trace waves, for comparison)
     int direct_slots = 1;               // pipeline 3: the primary kernel shades the camera rays' hits itself (no shade(0) launch, no queue)
@@ -122,6 +125,8 @@ struct rtw_scene {
     rtw_context* ctx = nullptr;
     std::vector<std::unique_ptr<rtw::HostMesh>> meshes;
     bool committed = false;
+    bool has_emissive = false;          // some material tree holds an Emissive node
+    bool materials_finite = true;       // every material colour and parameter is a finite number
     bool has_analytic = false;          // some shape is a sphere / plane / capsule
     bool texture_carry = false;         // ... and comes after a textured mesh: its hits can inherit that mesh's sampled colour
                                         // (one RayHitResult serves all shapes, Src/RayTracerScene.cpp:99-125) -> single-kernel pipeline
@@ -264,6 +269,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "finish_in_trace") == 0) { ctx->finish_in_trace = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "batch_passes") == 0) { ctx->batch_passes = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "resolve_inline") == 0) { ctx->resolve_inline = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "lead_split") == 0) { ctx->lead_split = value ? 1 : 0; return RTW_OK; }
@@ -579,6 +585,10 @@ int rtw_scene_commit(rtw_scene* scene)
         d.has_material = m.material.empty() ? 0 : 1;
         d.n_material_nodes = (int)m.material.size();
         for (size_t k = 0; k < m.material.size(); k++) d.material[k] = m.material[k];
+        for (const RtwMaterialNode& mn : m.material) {
+            if (mn.type == RTW_MAT_EMISSIVE) scene->has_emissive = true;
+            if (!std::isfinite(mn.r) || !std::isfinite(mn.g) || !std::isfinite(mn.b) || !std::isfinite(mn.param)) scene->materials_finite = false;
+        }
         d.kind = m.kind; d.radius = m.radius;
         for (int k = 0; k < 3; k++) { d.pa[k] = m.pa[k]; d.pb[k] = m.pb[k]; d.pc[k] = m.pc[k]; d.pn[k] = m.pn[k]; }
         d.pd1 = m.pd1;
@@ -1044,6 +1054,9 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
             tune.has_analytic = scene->has_analytic;
             tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();       // nothing is left for the trace kernels
         }
+        // no Emissive material anywhere, finite material colours, no preview, no counters: the last trace round can finish its paths
+        tune.finish_in_trace = cx->finish_in_trace && p.direct_slots && !scene->has_analytic && !scene->has_emissive && scene->materials_finite &&
+                               !p.preview && !cx->stats_enabled && max_bounce >= 2;
         tune.counters_clean = p.self_clean && cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
         cx->clean_ws = nullptr;
         e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);

@@ -560,3 +560,26 @@ def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, m
         a, b = fb.read_float(), fb.resolve_argb()
         assert (bits(a) == bits(ra)).all() and (b == rb).all(), batch
     ctx.set_option("batch_passes", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4), ("BlenderMonkey", 3, 2), ("TorusKnot", 2, 9)])
+def test_last_trace_round_that_finishes_its_paths_equals_a_last_shade_launch(ctx, mesh, ns, depth):
+    """When no material of the scene emits, a path whose last segment hits gets exactly 0 and one whose last segment misses the sky
+    colour, whatever the hit's shading inputs: the last trace round can fold the levels itself (option finish_in_trace; off by default,
+    it measured slower).
+    Same bits as with the last shade launch; a scene with an Emissive node keeps that launch (and equals the single kernel)."""
+    W, H = 1280, 720
+    mats = [R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5),
+            R.SurfaceMaterial_Combine(R.SurfaceMaterial_Diffuse((0.8, 0.8, 0.8)), R.SurfaceMaterial_Emissive((0.2, 0.1, 0.05)))]
+    for mat in mats:
+        s = gpu_scene(ctx, mesh, mat)
+        out = []
+        for finish, pipeline in ((1, 3), (0, 3), (1, 0)):
+            ctx.set_option("finish_in_trace", finish)
+            ctx.set_option("pipeline", pipeline)
+            out.append(render_frame(ctx, s, W, H, ns, depth, 0, 1357, 0, 2))
+        ctx.set_option("finish_in_trace", 0)
+        ctx.set_option("pipeline", 3)
+        for o in out[1:]:
+            assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
