@@ -1734,7 +1734,7 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
 }
 
 template <bool STATS, bool AN>
-__global__ __launch_bounds__(256) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int last)
+__global__ __launch_bounds__(256, 3) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int last)
 {
     __shared__ float thr[256];
     if (p.resolve_inline) { thr[threadIdx.x] = sc->gamma_thr[threadIdx.x]; __syncthreads(); }
