@@ -2062,10 +2062,13 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
                     hipLaunchKernelGGL((trace_wave_kernel<false, 0, NTV, false, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, p.resolve_inline ? 1 : 0);
                     break;
                 }
+#ifndef RTW_LEAD_CHUNK_SHIFT_MAX
+#define RTW_LEAD_CHUNK_SHIFT_MAX 2      /* measured on SetupScene: 4 entries per wave at a time 1.64 ms, 16: 1.67, 64: 1.84, 1: 1.80 (flagged rays cluster: small chunks spread them over the waves) */
+#endif
                 if (p.lead_shapes > 0) {        // leading analytic shapes: the records are half done, most rays need no trace (see trace_wave_lead_kernel)
                     constexpr int NTV = 128;
                     int shift = 0;
-                    while (shift < 6 && (rays >> (shift + 1)) >= 16384) shift++;
+                    while (shift < RTW_LEAD_CHUNK_SHIFT_MAX && (rays >> (shift + 1)) >= 16384) shift++;
                     long long blocks = ((rays >> shift) + NTV / 64) / (NTV / 64);
                     const long long cap = (long long)tune.wave_blocks * (1024 / NTV) * tune.wave_blocks_mul;
                     if (blocks < 1) blocks = 1;
