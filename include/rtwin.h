@@ -86,7 +86,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   2 = packet walk for camera rays + a 16-lanes-per-ray trace and a shade launch per bounce;
  *                   1 = packet walk + one path kernel + resolve; 0 = one kernel, one thread per pixel.
  *   pipeline 3:     "direct_slots" (1) camera-ray hits are shaded by the primary kernel; "batch_passes" (1) the passes of one rtw_render_passes call fork the second stream once and join it once;
- *                   "finish_in_trace" (0) when no material emits, the last trace round ends its paths itself (no last shade launch; slower);
+ *                   "auto_fused" (1) below about 10 k queued paths per pass (a rank's share of a small frame) the one-kernel-
+ *                   for-all-bounces variant is used; "finish_in_trace" (0) when no material emits, the last trace round ends its paths itself (no last shade launch; slower);
  *                   "resolve_inline" (1) with one sample per pixel the lane that ends a path resolves its pixel (no resolve
  *                   launch); "lead_split" (1) the scene's leading spheres / planes / capsules are tested by
  *                   the lane that sets a segment up, the trace waves continue from its record; "sky_split" (1) sky-only tiles

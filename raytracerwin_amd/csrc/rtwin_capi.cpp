@@ -65,6 +65,8 @@ struct rtw_context {
     int batch_pos = 0;                  // rtw_render_passes: 0 = a pass on its own, 1 = first of a run, 2 = inside a run, 3 = last of a run
     bool aux_unjoined = false;          // a sky kernel of the current run is not joined yet
     int batch_passes = 1;               // 0: every pass forks and joins the second stream by itself (for comparison)
+    int auto_fused = 1;                 // pipeline 3: below ~10 k queued paths per pass use the one-kernel-for-all-bounces variant (see render_common)
+    bool auto_fused_on = false;
     int finish_in_trace = 0;            // pipeline 3: 1 = the last trace round folds its paths' levels itself when no material emits (measured slower: the fold
                                         // is one lane's dependent loads per ray in a wave-per-ray loop; a shade launch does it a path per lane)
     int resolve_inline = 1;             // pipeline 3, one sample per pixel: a path's last shading step resolves its pixel (0: the resolve kernel does)
@@ -269,6 +271,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "auto_fused") == 0) { ctx->auto_fused = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "finish_in_trace") == 0) { ctx->finish_in_trace = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "batch_passes") == 0) { ctx->batch_passes = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "resolve_inline") == 0) { ctx->resolve_inline = value ? 1 : 0; return RTW_OK; }
@@ -1015,7 +1018,14 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         tune.sky_job0 = sky_job0; tune.gamma_thr = cx->d_gamma;
         tune.do_fork = cx->batch_pos == 0 || cx->batch_pos == 1 || !cx->aux_unjoined;      // (a run whose earlier passes launched no sky kernel has not forked yet)
         tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
-        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = cx->wave_fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.trace_block = cx->trace_block; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
+        // Few paths (a rank's share of a small frame at 8 or more ranks): every launch of the per-bounce pipeline sits on its ~9 us floor, and the
+        // one-kernel-for-all-bounces variant, slower at full size, wins (C2 at 8 ranks: 0.074 vs 0.080 ms per pass).  Chosen from the previous pass's
+        // queue length, with some hysteresis (the two variants count the queue a little differently).
+        int fused = cx->wave_fused;
+        if (!fused && !cx->wave_tail && cx->auto_fused && pipeline == 3 && !scene->has_analytic && !capturing && !cx->stats_enabled && !cx->kernel_timing &&
+            tune.expected_paths >= 0 && tune.expected_paths < (cx->auto_fused_on ? 13000 : 10000)) fused = 1;
+        cx->auto_fused_on = fused && !cx->wave_fused;
+        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.trace_block = cx->trace_block; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
         if (p.wavefront == 2 && !scene->meshes.empty()) {
             // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
             const rtw::HostMesh& m0 = *scene->meshes[0];
@@ -1044,7 +1054,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         tune.path_variant = cx->path_variant;
         const size_t coff = rtw::pipeline_counters_offset(p.count, max_bounce);
         p.self_clean = p.wavefront == 2 ? 1 : 0;
-        p.direct_slots = (p.wavefront == 2 && cx->direct_slots && !cx->wave_fused && !cx->wave_tail) ? 1 : 0;
+        p.direct_slots = (p.wavefront == 2 && cx->direct_slots && !fused && !cx->wave_tail) ? 1 : 0;
         // one sample per pixel: the lane that ends a path resolves its pixel (no pending list, no resolve launch)
         p.resolve_inline = (p.direct_slots && cx->resolve_inline && sub_samples == 1 && max_bounce >= 2) ? 1 : 0;
         {   // leading spheres / planes / capsules are tested by the lane that sets a segment up (see RtwRenderParams::lead_shapes)

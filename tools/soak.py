@@ -101,12 +101,12 @@ def run(seed_arg, cases, ctx=None, log=print):
         prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 4))
         world, rows = int(rng.choice([1, 1, 2, 3, 8])), int(rng.choice([10, 10, 7, 16, 1]))
         opts = dict(direct_slots=int(rng.random() < 0.8), sky_split=int(rng.random() < 0.8), wave_stage=int(rng.choice([0, 0, 0, 1, 2, 3, -1])),
-                    trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3), lead_split=int(rng.random() < 0.8), resolve_inline=int(rng.random() < 0.8), batch_passes=int(rng.random() < 0.7), finish_in_trace=int(rng.random() < 0.4))
+                    trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3), lead_split=int(rng.random() < 0.8), resolve_inline=int(rng.random() < 0.8), batch_passes=int(rng.random() < 0.7), finish_in_trace=int(rng.random() < 0.4), auto_fused=int(rng.random() < 0.7))
         res = []
         for pl in (0, 3):
             ctx.set_option("pipeline", pl)
             for k, v in opts.items():
-                ctx.set_option(k, v if pl == 3 else dict(direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1, finish_in_trace=0)[k])
+                ctx.set_option(k, v if pl == 3 else dict(direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1, finish_in_trace=0, auto_fused=1)[k])
             fb = R.Framebuffer(ctx, W, H)
             for rank in range(world):
                 if pl == 3 and (opts["use_graph"] or opts["batch_passes"]):
@@ -120,7 +120,7 @@ def run(seed_arg, cases, ctx=None, log=print):
         ok = bool((res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all())
         bad += not ok
         log(it, kind, W, H, "spp", spp, "d", depth, "prev", prev, "passes", npass, "world", world, "rows", rows, opts, "OK" if ok else "DIFF", flush=True)
-    for k, v in dict(pipeline=3, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1, finish_in_trace=0).items():
+    for k, v in dict(pipeline=3, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1, finish_in_trace=0, auto_fused=1).items():
         ctx.set_option(k, v)
     log("soak done, seed", seed_arg, "mismatches:", bad)
     return bad
