@@ -277,6 +277,10 @@ class Context:
         _check(library().rtw_last_pass_kernel_ms(self.h, out))
         return [float(v) for v in out]
 
+    def last_pass_pipeline(self):
+        """the pipeline the latest render call actually ran (a fallback shows here)"""
+        return int(library().rtw_last_pass_pipeline(self.h))
+
     def stats_enable(self, on=True):
         _check(library().rtw_stats_enable(self.h, int(on)))
 

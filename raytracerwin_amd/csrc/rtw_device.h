@@ -55,6 +55,23 @@ struct PipelineTuning {
 int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream);
 // device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)
 size_t pipeline_counters_offset(long long work_items, int max_bounce);
+// ---- pass-batched pipeline (pipeline 4, rtw_group_kernels.h) ----
+struct GroupLayout { size_t counters_off, rad_off, state_off, hit_off, carry_off, levels_off, list0_off, list1_off, total; };
+// device bytes of a group's workspace: `capacity` path slots (busy tiles x 64 x sub-samples x passes of the group, rounded up to a power of two of passes)
+size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupLayout* out);
+struct GroupTuning {
+    size_t capacity = 0;
+    hipStream_t aux_stream = nullptr; hipEvent_t fork_event = nullptr, join_event = nullptr;   // sky-only tiles run on aux_stream beside the rest of the group
+    bool do_fork = true, do_join = true; bool* aux_unjoined = nullptr;
+    const float* gamma_thr = nullptr;
+    bool has_analytic = false;     // some shape is a sphere / plane / capsule / triangle
+    bool carry = false;            // ... and one of them follows a textured mesh: hit records carry the mesh hit whose texel the hit keeps
+    bool counters_clean = false;   // the list counters are zero (left so by the previous group)
+    int round_hint[32];            // list lengths of the previous group per round (-1 = unknown): they size the launches
+    int cu_count = 256;
+    hipEvent_t* timing = nullptr;  // null, or 4 events: before the primary kernel, after it, after the bounce rounds, after resolve
+};
+int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwGroupParams& g, const GroupTuning& tune, bool stats, hipStream_t stream);
 #define RTW_LDS_WIDE_BUDGET 160   // 16-wide nodes (448 B each) that may be staged in LDS: 70 KiB -> two 256-thread blocks per CU
 #define RTW_LDS_QUAD_BUDGET 1024  // quads (128 B each) that may be staged in LDS beside the per-quartet trails and lists
 int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream);

@@ -1839,6 +1839,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restric
 
 #ifndef RTW_HOST_EMUL
 #include "rtw_wave_kernels.h"
+#include "rtw_group_kernels.h"
 #endif
 
 __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
@@ -2223,6 +2224,108 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
     if (!p.resolve_inline) hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     if (forked && tune.do_join) {           // the pass (or the run of passes) is complete when both streams are
+        (void)hipStreamWaitEvent(stream, tune.join_event, 0);
+        if (tune.aux_unjoined) *tune.aux_unjoined = false;
+    }
+    if (tune.timing) (void)hipEventRecord(tune.timing[3], stream);
+    return (int)hipGetLastError();
+}
+
+// ---- pass-batched pipeline (rtw_group_kernels.h) -----------------------------------------------------------------------------
+size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupLayout* out)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t cap = capacity > 0 ? capacity : 1;
+    GroupLayout l;
+    l.counters_off = 0;                         // 128 words at the start: the offset never moves when the workspace grows
+    l.rad_off = 1024;
+    l.state_off = l.rad_off + up(cap * 16);
+    l.hit_off = l.state_off + up(cap * 48);
+    l.carry_off = l.hit_off + up(cap * 32);
+    l.levels_off = l.carry_off + (carry ? up(cap * 16) : 0);
+    l.list0_off = l.levels_off + up(cap * (size_t)(max_bounce > 0 ? max_bounce : 1) * 48);
+    l.list1_off = l.list0_off + up(cap * 4);
+    l.total = l.list1_off + up(cap * 4);
+    if (out) *out = l;
+    return l.total;
+}
+
+int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwGroupParams& g, const GroupTuning& tune, bool stats, hipStream_t stream)
+{
+    const RtwRenderParams& p = g.rp;
+    if (g.n_passes <= 0 || (g.n_busy <= 0 && g.n_sky <= 0)) return 0;
+    GroupLayout l;
+    group_workspace_bytes(tune.capacity, p.max_bounce, tune.carry, &l);
+    char* w = (char*)workspace;
+    GroupBufs gb;
+    gb.rad = (float4*)(w + l.rad_off); gb.state = (float4*)(w + l.state_off); gb.hit = (float4*)(w + l.hit_off);
+    gb.carry = tune.carry ? (float4*)(w + l.carry_off) : nullptr; gb.levels = (float4*)(w + l.levels_off);
+    gb.list0 = (uint32_t*)(w + l.list0_off); gb.list1 = (uint32_t*)(w + l.list1_off); gb.counters = (uint32_t*)(w + l.counters_off);
+    gb.capacity = (uint32_t)tune.capacity; gb.carry_on = tune.carry ? 1 : 0;
+    if (!tune.counters_clean) { hipError_t e = hipMemsetAsync(gb.counters, 0, 256, stream); if (e != hipSuccess) return (int)e; }
+    bool forked = false;
+    if (g.n_sky > 0) {
+        hipStream_t ss = stream;
+        if (tune.aux_stream) {
+            forked = !tune.do_fork || (hipEventRecord(tune.fork_event, stream) == hipSuccess && hipStreamWaitEvent(tune.aux_stream, tune.fork_event, 0) == hipSuccess);
+            if (forked) ss = tune.aux_stream;
+        }
+        int sgrid = (g.n_sky + 3) / 4;
+        if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
+        hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, ss, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, g);
+        if (forked) {
+            if (tune.do_join) (void)hipEventRecord(tune.join_event, tune.aux_stream);
+            else if (tune.aux_unjoined) *tune.aux_unjoined = true;
+        }
+    }
+    if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
+    if (g.n_busy > 0) {
+        const long long live_paths = (long long)g.n_busy * 64 * p.sub_samples * g.n_passes;
+        {
+            const long long waves = (long long)g.n_jobs * g.n_passes;
+            const unsigned pgrid = (unsigned)((waves + 3) / 4);
+            if (tune.has_analytic) {
+                if (stats) hipLaunchKernelGGL((gprimary_kernel<true, true>), dim3(pgrid), dim3(256), 0, stream, sc, gb, g);
+                else hipLaunchKernelGGL((gprimary_kernel<false, true>), dim3(pgrid), dim3(256), 0, stream, sc, gb, g);
+            } else {
+                if (stats) hipLaunchKernelGGL((gprimary_kernel<true, false>), dim3(pgrid), dim3(256), 0, stream, sc, gb, g);
+                else hipLaunchKernelGGL((gprimary_kernel<false, false>), dim3(pgrid), dim3(256), 0, stream, sc, gb, g);
+            }
+        }
+        if (tune.timing) (void)hipEventRecord(tune.timing[1], stream);
+        auto blocks_for = [&](int list_round) {      // blocks of 256 lanes for the paths of list `list_round` (a grid-stride loop takes any excess)
+            long long items = live_paths;
+            if (tune.round_hint[list_round] >= 0) {
+                const long long want = (long long)tune.round_hint[list_round] + tune.round_hint[list_round] / 4 + 1024;
+                if (want < items) items = want;
+            }
+            long long bl = (items + 255) / 256;
+            if (bl < 1) bl = 1;
+            if (bl > 65536) bl = 65536;
+            return (unsigned)bl;
+        };
+        if (!p.preview) {
+            for (int r = 1; r < p.max_bounce; r++) {       // the primary kernel was shade(0); trace(r - 1) then shade(r)
+                const unsigned tb = blocks_for(r - 1);
+                if (tune.has_analytic) {
+                    if (stats) hipLaunchKernelGGL((gtrace_kernel<true, true>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
+                    else hipLaunchKernelGGL((gtrace_kernel<false, true>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
+                    if (stats) hipLaunchKernelGGL((gshade_kernel<true, true>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
+                    else hipLaunchKernelGGL((gshade_kernel<false, true>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
+                } else {
+                    if (stats) hipLaunchKernelGGL((gtrace_kernel<true, false>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
+                    else hipLaunchKernelGGL((gtrace_kernel<false, false>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
+                    if (stats) hipLaunchKernelGGL((gshade_kernel<true, false>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
+                    else hipLaunchKernelGGL((gshade_kernel<false, false>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
+                }
+            }
+        }
+        if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
+        hipLaunchKernelGGL(gresolve_kernel, dim3((unsigned)((g.n_busy + 3) / 4)), dim3(256), 0, stream, sc, (float4*)accum, (uint32_t*)argb, gb, g);
+    } else if (tune.timing) {
+        (void)hipEventRecord(tune.timing[1], stream); (void)hipEventRecord(tune.timing[2], stream);
+    }
+    if (forked && tune.do_join) {
         (void)hipStreamWaitEvent(stream, tune.join_event, 0);
         if (tune.aux_unjoined) *tune.aux_unjoined = false;
     }

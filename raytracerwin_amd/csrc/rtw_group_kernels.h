@@ -1,0 +1,564 @@
+// rtw_group_kernels.h -- the pass-batched pipeline (pipeline 4, the default).  Included inside rtw_device.hip's anonymous
+// namespace after rtw_wave_kernels.h; it uses that file's ray / triangle / shading helpers unchanged.
+//
+// The passes of the reference's sample loop (UpdateBitmapPixels, Src/RayTracerProgram.cpp:317-361) are independent apart from the
+// order in which a pixel's pass colours are added to its accumulator (AccumulatePixel::AddPixel, :51-75).  A GROUP of K consecutive
+// passes therefore shares one set of launches -- K times the rays per launch, 1 / K of the launches -- and every pixel's
+// accumulate + gamma + ARGB pack still runs once per pass, in pass order:
+//
+//   gsky_kernel      sky-only tiles (no leaf of any shape can be met from them): one lane per pixel, the K passes in a row with the
+//                    accumulator entry in registers (read once, written once per group), ARGB stored every pass.  Second stream.
+//   gprimary_kernel  one wave per (busy tile, pass[, sub-sample]): the camera rays through the tile's screen bin -- the bins walk of
+//                    primary_bins_kernel -- and the first shading step.  A path that ends writes its radiance, one that goes on saves
+//                    its state in its slot and joins round 0's ray list (ONE atomic per wave).
+//   gtrace_kernel    ONE LANE PER RAY over the reference's own binary tree in preorder (skip links, no stack): with K passes in one
+//                    launch there are enough rays to fill the chip a ray per lane, and a lane's node visit costs ~30 instructions
+//                    where a whole wave per ray spent ~450 per ray on mostly idle lanes.  Leaves whose box is hit are only NOTED
+//                    (a per-lane list in LDS); the triangle tests run afterwards, all lanes together, in list order = preorder, each
+//                    with the segment left by the previous accepted hit -- the reference's sequence (Src/KdTree.cpp:128-195).
+//   gshade_kernel    one lane per path: RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94).
+//   gresolve_kernel  one lane per pixel of the busy tiles: for each pass of the group in order, the pass colour from the samples'
+//                    radiances, AddPixel, GetGammaSpacePixel, ARGB store.
+//
+// Every float operation is the one the other pipelines execute, in the same order; the tests compare them bit for bit.
+
+#define RTW_GT_CAP 16           // candidate leaves a lane of gtrace_kernel notes before the wave runs its triangle tests
+
+struct GroupBufs {
+    float4* __restrict__ rad;       // [capacity]      radiance of a finished path
+    float4* __restrict__ state;     // [capacity * 3]  origin + distance | direction + draw counter | pixel, table reads, depth << 16 | levels, -
+    float4* __restrict__ hit;       // [capacity * 2]  hit position + distance | shape, leaf slot or part, carry shape, carry slot
+    float4* __restrict__ carry;     // [capacity]      texel-inheritance scenes: position of the mesh hit whose sampled colour the hit keeps
+    float4* __restrict__ levels;    // [capacity * max_bounce * 3]
+    uint32_t* __restrict__ list0;   // ray lists (slots), ping-pong
+    uint32_t* __restrict__ list1;
+    uint32_t* __restrict__ counters;// [r] = length of round r's list; [64 + r] = the same at the end of the previous group (for the host)
+    uint32_t capacity;
+    int32_t carry_on;               // the scene has an analytic shape after a textured mesh (Src/RRay.cpp:53-58,75-80: its hits keep the texel)
+};
+
+__device__ __forceinline__ uint32_t group_slot(const RtwGroupParams& g, uint32_t b, uint32_t lane, uint32_t sub, uint32_t k)
+{
+    return (((b * 64u + lane) * (uint32_t)g.rp.sub_samples + sub) << g.kshift) | k;
+}
+// pixel of (tile, lane); false: the lane has no pixel (past the frame's right / bottom edge, outside the rendered range)
+__device__ __forceinline__ bool group_xy(const RtwGroupParams& g, int wt, int lane, int& x, int& y)
+{
+    bool live = work_to_xy(g.rp, wt * 64 + lane, x, y);
+    live = live && x < g.rp.width;
+    const int pixel = y * g.rp.width + x;
+    return live && pixel >= g.range_begin && pixel <= g.range_end;
+}
+
+// RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94) for one path whose segment has just been traced (r0 = hit position +
+// distance, r1 = shape, leaf slot or part, carry).  Returns true when the path goes on (ray, rng, depth, nlev updated, its level
+// pushed); false when it ends: L is its radiance, the levels folded back in the reference's association order.
+template <bool STATS, bool AN>
+__device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__ sc, const RtwRenderParams& p, const GroupBufs& gb, uint32_t slot,
+                                                 Ray& ray, PathRng& rng, int& depth, int& nlev, float4 r0, float4 r1, float4 r2, f3& L, Counters& ct)
+{
+    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
+    if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
+    LevelStore lv; lv.ws = gb.levels; lv.stride = (size_t)gb.capacity; lv.tid = (size_t)slot; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
+    L = mk(0, 0, 0);
+    bool done = false;
+    const int hs = __float_as_int(r1.x), hslot = __float_as_int(r1.y);
+    if (hs < 0) { L = sky_color(ray.d.y); done = true; }
+    else {
+        const RtwShapeDev& sh = sc->shapes[hs];
+        Hit h; int tri_index;
+        if (AN) {
+            hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, hslot, h, tri_index, ct);
+            // one RayHitResult serves all shapes of a query (Src/RayTracerScene.cpp:99-125): a sphere / plane / capsule-side / RTriangle hit keeps
+            // the sampled colour and alpha an earlier mesh hit of the same query left there
+            const int cs = __float_as_int(r1.z);
+            if (gb.carry_on && sh.kind != RTW_SHAPE_MESH && hslot == 0 && cs >= 0) {
+                Hit hc; int ti; Counters none = { 0, 0, 0, 0, 0, 0 };
+                mesh_finish<false>(sc, sc->shapes[cs], tc, mk(r2.x, r2.y, r2.z), r2.w, __float_as_int(r1.w), hc, ti, none);
+                h.color = hc.color; h.alpha = hc.alpha;
+            }
+        } else {
+            mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, hslot, h, tri_index, ct);
+        }
+        if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
+        else {
+            Ray out = ray;
+            if (p.preview) {
+                const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
+                L = mk(0, 0, 0) + pv.att * h.color; done = true;
+            } else {
+                const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
+                if (rng.random() <= h.alpha) {
+                    if (all_nonzero(b.att)) {
+                        lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
+                        lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                        lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+                        nlev++;
+                        ray = out;
+                    } else { L = mk(0, 0, 0) + b.em; done = true; }
+                } else {                 // transparent texel: same direction, remaining distance, no colour factor
+                    lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+                    nlev++;
+                    const float rd = ray.dist - h.dist;
+                    ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
+                }
+                if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
+            }
+        }
+    }
+    if (!done) return true;
+    for (int kk = nlev - 1; kk >= 0; kk--) {
+        const float4 a = lv.at(kk, 0);
+        if (__float_as_int(a.w) == 0) {
+            const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
+            L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
+        } else {
+            L = mk(0, 0, 0) + L;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ void group_save_state(const GroupBufs& gb, uint32_t slot, const Ray& ray, const PathRng& rng, int depth, int nlev, int pixel)
+{
+    gb.state[(size_t)slot * 3] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
+    gb.state[(size_t)slot * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
+    gb.state[(size_t)slot * 3 + 2] = make_float4(__int_as_float(pixel), __uint_as_float(rng.table_reads),
+                                                 __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
+}
+
+// ---- sky-only tiles: K passes per pixel with the accumulator entry in registers ----------------------------------------------
+__global__ __launch_bounds__(256) void gsky_kernel(const float* __restrict__ gamma_thr, float4* __restrict__ accum, uint32_t* __restrict__ argb, RtwGroupParams g)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = gamma_thr[threadIdx.x];
+    __syncthreads();
+    const RtwRenderParams& p = g.rp;
+    const int npix = p.width * p.height;
+    const uint32_t phase = table_phase(p.seed);
+    const int wave0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int wk = wave0; wk < g.n_sky; wk += nwaves) {
+        const int wt = (int)cldu(g.sky_tiles, wk);
+        int px = 0, py = 0;
+        if (!group_xy(g, wt, lane_id(), px, py)) continue;
+        const int pixel = py * p.width + px;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.preview) acc = accum[pixel];
+        f3 sum = mk(acc.x, acc.y, acc.z);
+        int n = __float_as_int(acc.w);
+        for (int k = 0; k < g.n_passes; k++) {
+            f3 csum = mk(0, 0, 0);
+            for (int i = 0; i < p.sub_samples; i++) {
+                PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)(g.first_pass + k), (uint32_t)i);
+                const Ray ray = camera_ray_xy(p, px, py, i, rng);
+                const f3 si = p.max_bounce != 0 ? sky_color(ray.d.y) : mk(0, 0, 0);       // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+                csum = csum + si;
+            }
+            const f3 c = p.sub_samples == 1 ? csum : csum / (float)p.sub_samples;          // x / 1.0f == x
+            uint32_t packed;
+            if (p.preview) packed = pack_pixel(thr, c);
+            else { sum = sum + c; n++; packed = pack_pixel(thr, n == 1 ? sum : sum / (float)n); }
+            __builtin_nontemporal_store(packed, &argb[pixel]);      // bitcolor[] is written every pass (Src/RayTracerProgram.cpp:185)
+        }
+        if (!p.preview) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+    }
+}
+
+// ---- camera rays of the busy tiles + first shading step -------------------------------------------------------------------------
+template <bool STATS, bool AN>
+__global__ __launch_bounds__(256) void gprimary_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, RtwGroupParams g)
+{
+    const RtwRenderParams& p = g.rp;
+    const int npix = p.width * p.height;
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    const uint32_t phase = table_phase(p.seed);
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    const uint32_t total = (uint32_t)g.n_jobs * (uint32_t)g.n_passes;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wave < total) {
+        // the passes of a tile are neighbouring waves (its bin list stays hot); jobs in the table's order, heaviest bins first
+        const uint32_t jidx = wave / (uint32_t)g.n_passes, kpass = wave - jidx * (uint32_t)g.n_passes;
+        const uint32_t job = g.jobs ? cldu(g.jobs, (int)jidx) : jidx;
+        const uint32_t b = job & 0xFFFFFFu;
+        const int only_sample = (int)((job >> 24) & 15u) - 1;        // -1: this wave does every sub-sample of its tile
+        const int wt = g.busy_tiles ? (int)cldu(g.busy_tiles, (int)b) : g.first_tile + (int)b;
+        const int pass = g.first_pass + (int)kpass;
+        const int lane = lane_id();
+        int px = 0, py = 0;
+        const bool live = group_xy(g, wt, lane, px, py);
+        if (!live) { px = 0; py = 0; }
+        const int pixel = live ? py * p.width + px : 0;
+        // the wave's bin: all its pixels lie in one tile of the screen's bin grid (tile rows never straddle a bin row); a tile with a
+        // live lane starts inside the frame (its first lane has the tile's smallest x and y)
+        int bin = 0;
+        if (__ballot(live) != 0ull) {
+            int tx = 0, ty = 0;
+            (void)work_to_xy(p, wt * 64, tx, ty);
+            bin = (ty >> (6 - p.tile_shift)) * p.tiles_per_row + (tx >> p.tile_shift);
+        }
+        bool near_wave = false;          // can any sample of this wave's pixels hit anything?
+        for (int k = 0; k < n_shapes; k++) {
+            const uint32_t* __restrict__ boff = p.bins[k].off;
+            near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);
+        }
+        uint32_t queued = 0u;
+        for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
+            if (only_sample >= 0 && i != only_sample) continue;
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass, (uint32_t)i);
+            const Ray ray = camera_ray_xy(p, px, py, i, rng);
+            if (STATS && live) ct.cams++;
+            const uint32_t slot = group_slot(g, b, (uint32_t)lane, (uint32_t)i, kpass);
+            f3 si = mk(0, 0, 0);
+            bool have_hit = false;
+            float4 hr0 = make_float4(0.f, 0.f, 0.f, 0.f), hr1 = hr0, hr2 = hr0;
+            if (p.max_bounce != 0 && !near_wave && !STATS) {     // no leaf of any shape can be met from this tile: every sample sees the sky
+                if (live) si = sky_color(ray.d.y);
+            } else if (p.max_bounce != 0) {                      // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
+                // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
+                int hit_shape = -1, hit_slot = -1, carry_shape = -1, carry_slot = -1;
+                f3 hit_pos = mk(0, 0, 0), carry_pos = mk(0, 0, 0);
+                float seg = ray.dist, carry_dist = 0.0f;
+                if (STATS && live) ct.rays++;
+                const bool tame = ray_is_tame(ray);
+                const bool any_untame = __ballot(live && !tame) != 0ull;
+                const bool skx = near_zero(ray.d.x), sky = near_zero(ray.d.y), skz = near_zero(ray.d.z);
+                for (int k = 0; k < n_shapes; k++) {
+                    const RtwShapeDev& sh = sc->shapes[k];
+                    const int kind = AN ? sh.kind : RTW_SHAPE_MESH;
+                    float t0, t1;
+                    const bool inbox = live && ((AN && kind == RTW_SHAPE_PLANE) ||      // a plane has no culling box (RPlane::HasCullingBounds)
+                                                slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1));
+                    if (STATS && live && kind != RTW_SHAPE_PLANE) ct.boxes++;
+                    if (__ballot(inbox) == 0ull) continue;
+                    float cur = seg; f3 pos = mk(0, 0, 0); int slot_hit = -1;
+                    bool any = false;
+                    const uint32_t* __restrict__ boff = p.bins[k].off;
+                    if (AN && kind != RTW_SHAPE_MESH) {          // a sphere / plane / capsule / triangle: every lane tests its own ray; slot = the part hit
+                        if (inbox) any = analytic_test(sh, ray, seg, pos, cur, slot_hit);
+                    } else if (boff == nullptr) {                // no bins for this shape: packet walk of its tree
+                        any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot_hit, ct);
+                        if (any_untame) {
+                            const bool a2 = packet_walk<STATS, true>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && !tame, false, cur, pos, slot_hit, ct);
+                            any = any || a2;
+                        }
+                    } else {
+                        const bool active = inbox && tame;
+                        const bool active_exact = inbox && !tame;
+                        const uint32_t* __restrict__ bent = p.bins[k].ent;
+                        const int e0 = (int)cldu(boff, bin), e1 = (int)cldu(boff, bin + 1);
+                        const float4* nd4 = reinterpret_cast<const float4*>(sh.nodes);
+                        const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+                        const float ix = (!tame && skx) ? 0.0f : 1.0f / ray.d.x, iy = (!tame && sky) ? 0.0f : 1.0f / ray.d.y, iz = (!tame && skz) ? 0.0f : 1.0f / ray.d.z;
+                        const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+                        // 64 entries at a time: lane j fetches entry j's leaf box and triangle record (all loads in flight together),
+                        // then the wave goes through the entries in order and every lane tests its own ray against the broadcast record
+                        for (int ec = e0; ec < e1; ec += 64) {
+                            const int cnt = e1 - ec < 64 ? e1 - ec : 64;
+                            const int mnode = lane < cnt ? (int)bent[ec + lane] : 0;
+                            const float4 mlo = gld4(nd4, 2 * (size_t)mnode), mhi = gld4(nd4, 2 * (size_t)mnode + 1);
+                            const int mleaf = __float_as_int(mhi.w) < 0 ? 0 : __float_as_int(mhi.w);
+                            const float4 ta = gld4(tr4, 4 * (size_t)mleaf), tb = gld4(tr4, 4 * (size_t)mleaf + 1), tc = gld4(tr4, 4 * (size_t)mleaf + 2);
+                            const float td = gld4(tr4, 4 * (size_t)mleaf + 3).x;
+                            for (int j = 0; j < cnt; j++) {
+                                const float lox = readlane_f(mlo.x, j), loy = readlane_f(mlo.y, j), loz = readlane_f(mlo.z, j);
+                                const float hix = readlane_f(mhi.x, j), hiy = readlane_f(mhi.y, j), hiz = readlane_f(mhi.z, j);
+                                const float x1 = (lox - ray.o.x) * ix, x2 = (hix - ray.o.x) * ix;
+                                const float y1 = (loy - ray.o.y) * iy, y2 = (hiy - ray.o.y) * iy;
+                                const float z1 = (loz - ray.o.z) * iz, z2 = (hiz - ray.o.z) * iz;
+                                const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                                const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                                bool hit = active && (tmax > tmin);
+                                if (prune) hit = hit && !(tmin > cur + (eps_t + 1.0e-4f * cur)) && !(tmax < -eps_t);
+                                if (any_untame) {                // wave-uniform: RRay::TestIntersectionWithAabb as written for the lanes that need it
+                                    float emin = -FLT_MAX, emax = FLT_MAX;
+                                    if (!skx) { emin = ref_max(emin, ref_min(x1, x2)); emax = ref_min(emax, ref_max(x1, x2)); }
+                                    if (!sky) { emin = ref_max(emin, ref_min(y1, y2)); emax = ref_min(emax, ref_max(y1, y2)); }
+                                    if (!skz) { emin = ref_max(emin, ref_min(z1, z2)); emax = ref_min(emax, ref_max(z1, z2)); }
+                                    if (active_exact) hit = emax > emin;
+                                }
+                                if (STATS) ct.boxes += (active || active_exact) ? 1u : 0u;
+                                if (__ballot(hit) == 0ull) continue;
+                                const int leaf = __builtin_amdgcn_readlane(mleaf, j);
+                                const float4 a = make_float4(readlane_f(ta.x, j), readlane_f(ta.y, j), readlane_f(ta.z, j), readlane_f(ta.w, j));
+                                const float4 bq = make_float4(readlane_f(tb.x, j), readlane_f(tb.y, j), readlane_f(tb.z, j), readlane_f(tb.w, j));
+                                const float4 c = make_float4(readlane_f(tc.x, j), readlane_f(tc.y, j), readlane_f(tc.z, j), readlane_f(tc.w, j));
+                                const float d1 = readlane_f(td, j);
+                                if (hit) {
+                                    if (STATS) ct.tris++;
+                                    f3 cp; float dist;
+                                    if (triangle_test(ray, cur, a, bq, c, d1, cp, dist)) { cur = dist; pos = cp; slot_hit = leaf; any = true; }
+                                }
+                            }
+                        }
+                    }
+                    if (any) {
+                        seg = cur; hit_shape = k; hit_slot = slot_hit; hit_pos = pos;
+                        if (AN && kind == RTW_SHAPE_MESH) { carry_shape = k; carry_slot = slot_hit; carry_pos = pos; carry_dist = cur; }
+                        else if (AN && slot_hit != 0) carry_shape = -1;      // a capsule end resets the sampled colour (Src/Shapes.cpp:34-62)
+                    }
+                }
+                if (live) {
+                    if (hit_shape < 0) si = sky_color(ray.d.y);
+                    else {
+                        have_hit = true;
+                        hr0 = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
+                        hr1 = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), __int_as_float(carry_shape), __int_as_float(carry_slot));
+                        hr2 = make_float4(carry_pos.x, carry_pos.y, carry_pos.z, carry_dist);
+                    }
+                }
+            }
+            if (have_hit) {                                      // shade the hit here: the path's slot needs no queue position
+                Ray r = ray; PathRng rg = rng; int depth = p.max_bounce, nlev = 0;
+                f3 L;
+                if (group_shade_step<STATS, AN>(sc, p, gb, slot, r, rg, depth, nlev, hr0, hr1, hr2, L, ct)) {
+                    group_save_state(gb, slot, r, rg, depth, nlev, pixel);
+                    queued |= 1u << i;
+                } else {
+                    si = mk(0, 0, 0) + L;
+                    gb.rad[slot] = make_float4(si.x, si.y, si.z, 0.0f);
+                }
+            } else if (live) {
+                gb.rad[slot] = make_float4(si.x, si.y, si.z, 0.0f);
+            }
+        }
+        // ONE atomic per wave: round 0's list gets an entry per sample that goes on
+        const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
+                                 m3 = __ballot((queued & 8u) != 0u);
+        if ((m0 | m1 | m2 | m3) != 0ull) {
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(&gb.counters[0], c0 + c1 + c2 + c3);
+            const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (queued & 1u) gb.list0[qb + (uint32_t)mbcnt(m0)] = group_slot(g, b, (uint32_t)lane, 0u, kpass);
+            if (queued & 2u) gb.list0[qb + c0 + (uint32_t)mbcnt(m1)] = group_slot(g, b, (uint32_t)lane, 1u, kpass);
+            if (queued & 4u) gb.list0[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = group_slot(g, b, (uint32_t)lane, 2u, kpass);
+            if (queued & 8u) gb.list0[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = group_slot(g, b, (uint32_t)lane, 3u, kpass);
+        }
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+// ---- one round of secondary segments: a ray per lane --------------------------------------------------------------------------
+// The reference's box test of one node for one lane's ray (RRay::TestIntersectionWithAabb, Src/RRay.cpp:89-136): tame rays through
+// hoisted reciprocals and v_min / v_max (the same values), the others -- a direction component below FLT_EPSILON, NaN, ... -- with
+// the test as written (skipped axes, Math::Min / Max ternaries); the conservative segment clip only for tame rays.
+struct LaneRay { f3 o; float ix, iy, iz, eps_t; bool tame, skx, sky, skz; };
+__device__ __forceinline__ LaneRay lane_ray_of(const Ray& r)
+{
+    LaneRay q;
+    q.o = r.o;
+    q.tame = ray_is_tame(r);
+    q.skx = near_zero(r.d.x); q.sky = near_zero(r.d.y); q.skz = near_zero(r.d.z);
+    q.ix = (!q.tame && q.skx) ? 0.0f : 1.0f / r.d.x; q.iy = (!q.tame && q.sky) ? 0.0f : 1.0f / r.d.y; q.iz = (!q.tame && q.skz) ? 0.0f : 1.0f / r.d.z;
+    q.eps_t = 2.0e-5f * fmaxf(fabsf(q.ix), fmaxf(fabsf(q.iy), fabsf(q.iz)));
+    return q;
+}
+
+// KdNode::TestRayIntersection (Src/KdTree.cpp:128-195) of every lane's own ray on one mesh: the preorder walk of tree_walk with the
+// triangle tests postponed.  `go`: this lane's ray passed the shape's culling box.  On return cur / pos / leaf hold what the
+// reference's recursion leaves in TestRay.Distance / *OutResult / *TriangleIndex.
+template <bool STATS>
+__device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* __restrict__ cand, const Ray& r, const LaneRay& q, bool go, bool prune,
+                                               float& cur, f3& pos, int& leaf_out, Counters& ct)
+{
+    const float4* nd4 = reinterpret_cast<const float4*>(sh.nodes);
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    const int n_nodes = sh.n_nodes;
+    const int tid = (int)threadIdx.x;
+    const bool any_untame = __ballot(go && !q.tame) != 0ull;
+    bool any = false;
+    int i = go ? 0 : n_nodes;
+    int ncand = 0;
+    for (;;) {
+        const bool walking = i < n_nodes;
+        const bool more = __ballot(walking) != 0ull;
+        if (walking) {
+            const float4 lo = gld4(nd4, 2 * (size_t)i), hi = gld4(nd4, 2 * (size_t)i + 1);
+            const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+            const float x1 = (lo.x - q.o.x) * q.ix, x2 = (hi.x - q.o.x) * q.ix;
+            const float y1 = (lo.y - q.o.y) * q.iy, y2 = (hi.y - q.o.y) * q.iy;
+            const float z1 = (lo.z - q.o.z) * q.iz, z2 = (hi.z - q.o.z) * q.iz;
+            const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+            const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+            bool hit = tmax > tmin;
+            if (prune) hit = hit && !(tmin > cur + (q.eps_t + 1.0e-4f * cur)) && !(tmax < -q.eps_t);
+            if (any_untame) {            // wave-uniform, rare
+                float emin = -FLT_MAX, emax = FLT_MAX;
+                if (!q.skx) { emin = ref_max(emin, ref_min(x1, x2)); emax = ref_min(emax, ref_max(x1, x2)); }
+                if (!q.sky) { emin = ref_max(emin, ref_min(y1, y2)); emax = ref_min(emax, ref_max(y1, y2)); }
+                if (!q.skz) { emin = ref_max(emin, ref_min(z1, z2)); emax = ref_min(emax, ref_max(z1, z2)); }
+                if (!q.tame) hit = emax > emin;
+            }
+            if (STATS) ct.boxes++;
+            if (hit && leaf >= 0) { lstu(cand, ncand * 256 + tid, (uint32_t)leaf); ncand++; }
+            i = (hit && leaf < 0) ? i + 1 : skip;
+        }
+        // the noted leaves' triangle tests: when some lane's list is full, and at the end of the walk
+        if (more && __ballot(ncand == RTW_GT_CAP) == 0ull) continue;
+        for (int j = 0; ; j++) {
+            const bool mine = j < ncand;
+            if (__ballot(mine) == 0ull) break;
+            if (mine) {
+                const int leaf = (int)lldu(cand, j * 256 + tid);
+                const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
+                if (STATS) ct.tris++;
+                f3 cp; float dist;
+                if (triangle_test(r, cur, a, b, c, d.x, cp, dist)) { cur = dist; pos = cp; leaf_out = leaf; any = true; }
+            }
+        }
+        ncand = 0;
+        if (!more) break;
+    }
+    return any;
+}
+
+// FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) of every lane's own ray, without the shading tail (only the record of
+// the last shape that hit is read afterwards; carry_* = the mesh hit whose sampled colour a later analytic hit keeps).
+template <bool STATS, bool AN>
+__device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ cand, const Ray& ray, bool have,
+                                                       int& hit_shape, int& hit_slot, f3& hit_pos, float& seg,
+                                                       int& carry_shape, int& carry_slot, f3& carry_pos, float& carry_dist, Counters& ct)
+{
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    const LaneRay q = lane_ray_of(ray);
+    if (STATS && have) ct.rays++;
+    for (int s = 0; s < n_shapes; s++) {
+        const RtwShapeDev& sh = sc->shapes[s];
+        const int kind = AN ? sh.kind : RTW_SHAPE_MESH;
+        float t0, t1;
+        const bool inbox = have && ((AN && kind == RTW_SHAPE_PLANE) ||
+                                    slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1));
+        if (STATS && have && kind != RTW_SHAPE_PLANE) ct.boxes++;
+        if (__ballot(inbox) == 0ull) continue;
+        float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
+        bool any = false;
+        if (AN && kind != RTW_SHAPE_MESH) {
+            if (inbox) any = analytic_test(sh, ray, seg, pos, cur, slot);
+        } else if (sh.n_nodes > 0) {
+            any = lane_mesh_walk<STATS>(sh, cand, ray, q, inbox, prune, cur, pos, slot, ct);
+        }
+        if (any) {
+            seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos;
+            if (AN && kind == RTW_SHAPE_MESH) { carry_shape = s; carry_slot = slot; carry_pos = pos; carry_dist = cur; }
+            else if (AN && slot != 0) carry_shape = -1;
+        }
+    }
+}
+
+template <bool STATS, bool AN>
+__global__ __launch_bounds__(256) void gtrace_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
+{
+    __shared__ uint32_t cand[RTW_GT_CAP * 256];
+    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
+    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
+    const uint32_t nthreads = gridDim.x * 256u;
+    const uint32_t lane = (uint32_t)lane_id();
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < n; base += nthreads) {     // wave-uniform
+        const uint32_t k = base + lane;
+        const bool have = k < n;
+        const uint32_t slot = have ? src[k] : 0u;
+        Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.dist = 0.0f;
+        if (have) {
+            const float4 s0 = gb.state[(size_t)slot * 3], s1 = gb.state[(size_t)slot * 3 + 1];
+            ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+        }
+        int hs = -1, hslot = -1, cs = -1, cslot = -1; f3 pos = mk(0, 0, 0), cpos = mk(0, 0, 0); float seg = ray.dist, cdist = 0.0f;
+        lane_find_intersection<STATS, AN>(sc, cand, ray, have, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct);
+        if (have) {
+            gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, seg);
+            gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(cs), __int_as_float(cslot));
+            if (AN && gb.carry_on) gb.carry[slot] = make_float4(cpos.x, cpos.y, cpos.z, cdist);
+        }
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+// ---- shading of one round's hits: a path per lane ---------------------------------------------------------------------------------
+template <bool STATS, bool AN>
+__global__ __launch_bounds__(256, 3) void gshade_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, RtwGroupParams g, int round)
+{
+    // round >= 1: the paths of list (round - 1) have had their segment traced; the ones that go on join list `round`
+    const RtwRenderParams& p = g.rp;
+    const uint32_t n = gb.counters[round - 1] < gb.capacity ? gb.counters[round - 1] : gb.capacity;
+    const uint32_t* __restrict__ src = (round - 1) & 1 ? gb.list1 : gb.list0;
+    uint32_t* __restrict__ dst = round & 1 ? gb.list1 : gb.list0;
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    const int npix = p.width * p.height;
+    const uint32_t phase = table_phase(p.seed);
+    const uint32_t kmask = (1u << g.kshift) - 1u;
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    const uint32_t trips = (n + nthreads - 1) / nthreads;        // wave-uniform trip count: every lane joins the pushes
+    for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < trips; it++, k += nthreads) {
+        const bool live = k < n;
+        const uint32_t slot = live ? src[k] : 0u;
+        bool go_on = false;
+        if (live && slot < gb.capacity) {
+            const float4 s0 = gb.state[(size_t)slot * 3], s1 = gb.state[(size_t)slot * 3 + 1], s2 = gb.state[(size_t)slot * 3 + 2];
+            Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+            const int pixel = __float_as_int(s2.x);
+            const uint32_t pass = (uint32_t)g.first_pass + (slot & kmask);
+            const uint32_t t = slot >> g.kshift;
+            uint32_t sub;
+            switch (p.sub_samples) { case 1: sub = 0u; break; case 2: sub = t & 1u; break; case 4: sub = t & 3u; break; default: sub = t - (t / 3u) * 3u; }
+            PathRng rng;
+            rng.key = stream_key(p.seed, (uint32_t)pixel, pass * 4u + sub);
+            rng.counter = __float_as_uint(s1.w); rng.table_reads = __float_as_uint(s2.y);
+            rng.table_base = (((uint64_t)pass * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
+            rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
+            int nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu), depth = (int)(__float_as_uint(s2.z) >> 16);
+            const float4 r0 = gb.hit[(size_t)slot * 2], r1 = gb.hit[(size_t)slot * 2 + 1];
+            float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (AN && gb.carry_on) r2 = gb.carry[slot];
+            f3 L;
+            go_on = group_shade_step<STATS, AN>(sc, p, gb, slot, ray, rng, depth, nlev, r0, r1, r2, L, ct);
+            if (go_on) group_save_state(gb, slot, ray, rng, depth, nlev, pixel);
+            else { const f3 c = mk(0, 0, 0) + L; gb.rad[slot] = make_float4(c.x, c.y, c.z, 0.0f); }
+        }
+        wave_push(dst, &gb.counters[round], go_on, slot);
+    }
+    if (STATS) flush_counters(sc, ct);
+}
+
+// ---- the group's pixels of the busy tiles: accumulate + resolve, pass by pass ---------------------------------------------------
+__global__ __launch_bounds__(256) void gresolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum, uint32_t* __restrict__ argb,
+                                                       GroupBufs gb, RtwGroupParams g)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
+    __syncthreads();
+    const RtwRenderParams& p = g.rp;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t >> 6, lane = t & 63u;
+    if (b < (uint32_t)g.n_busy) {
+        const int wt = g.busy_tiles ? (int)g.busy_tiles[b] : g.first_tile + (int)b;
+        int px = 0, py = 0;
+        if (group_xy(g, wt, (int)lane, px, py)) {
+            const int pixel = py * p.width + px;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!p.preview) acc = accum[pixel];
+            f3 sum = mk(acc.x, acc.y, acc.z);
+            int n = __float_as_int(acc.w);
+            for (int k = 0; k < g.n_passes; k++) {
+                f3 c = mk(0, 0, 0);
+                for (int i = 0; i < p.sub_samples; i++) {
+                    const float4 r = gb.rad[group_slot(g, b, lane, (uint32_t)i, (uint32_t)k)];
+                    c = c + mk(r.x, r.y, r.z);
+                }
+                c = c / (float)p.sub_samples;
+                uint32_t packed;
+                if (p.preview) packed = pack_pixel(thr, c);
+                else { sum = sum + c; n++; packed = pack_pixel(thr, n == 1 ? sum : sum / (float)n); }     // AddPixel + GetGammaSpacePixel
+                __builtin_nontemporal_store(packed, &argb[pixel]);
+            }
+            if (!p.preview) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+        }
+    }
+    // the group's last kernel: file the list lengths for the host (they size the next group's launches) and zero them
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        gb.counters[64 + threadIdx.x] = gb.counters[threadIdx.x];
+        gb.counters[threadIdx.x] = 0u;
+    }
+}

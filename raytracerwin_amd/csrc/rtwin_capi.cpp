@@ -80,7 +80,8 @@ struct rtw_context {
     bool stats_enabled = false;
     void* d_workspace = nullptr;        // per-launch queues / level store of the bounce recursion (grown on demand)
     size_t workspace_bytes = 0;
-    int pipeline = 3;                   // 3 = screen bins + a wave per secondary ray (default), 2 = a launch per bounce, 1 = primary / path / resolve, 0 = one kernel
+    int pipeline = 4;                   // 4 = pass-batched: screen bins + a ray per lane, K passes per set of launches (default), 3 = screen bins + a wave per secondary ray, one pass
+                                        // per set of launches, 2 = a launch per bounce, 1 = primary / path / resolve, 0 = one kernel
     int packets = 1;                    // pipeline 1: camera rays traced as 64-ray packets inside the primary kernel
     int path_lanes = 16;                // pipeline 1: lanes per ray in the path kernel (16, 4 or 1)
     uint32_t* h_counters = nullptr;     // pinned: queue / pending lengths copied back after each pass
@@ -121,6 +122,20 @@ struct rtw_context {
     int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
     int kernel_timing = 0;              // 1: record events around the three kernels of each pass
     hipEvent_t timing_events[4] = { nullptr, nullptr, nullptr, nullptr };
+    // pass-batched pipeline (pipeline 4): its own workspace (the list counters sit at its start and are left zeroed by every group)
+    void* d_group_ws = nullptr;
+    size_t group_ws_bytes = 0;
+    bool group_clean = false;
+    uint32_t* h_gcounters = nullptr;    // pinned: list lengths of a finished group
+    hipEvent_t gcounters_event = nullptr;
+    bool gcounters_pending = false;
+    struct GroupKey { const void* scene = nullptr; long long capacity = -1; int max_bounce = -1, preview = -1, n_passes = -1;
+                      bool operator==(const GroupKey& o) const { return scene == o.scene && capacity == o.capacity && max_bounce == o.max_bounce && preview == o.preview && n_passes == o.n_passes; } };
+    GroupKey gcounters_key, known_gkey;
+    int known_ground[32];
+    int group_paths = 2 << 20;          // passes are grouped until a launch holds about this many paths ...
+    int group_max = 16;                 // ... and at most this many passes (a power of two)
+    int last_pipeline = -1;             // the pipeline the latest render call actually ran (rtw_last_pass_pipeline)
 };
 
 struct rtw_scene {
@@ -138,9 +153,12 @@ struct rtw_scene {
     std::vector<void*> allocs;
     // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
     struct JobTable { int task_rows, rank, world, spp; const uint32_t* d_order; int n_jobs, n_busy; };     // n_busy: jobs of tiles with a non-empty bin (they come first)
+    // pass-batched pipeline: the launch's tiles split into busy ones (heaviest bins first) and sky-only ones, and the primary kernel's jobs
+    struct GroupTable { int task_rows, rank, world, spp; const uint32_t* d_busy; const uint32_t* d_sky; const uint32_t* d_jobs; int n_busy, n_sky, n_jobs; };
     struct BinSet { int width, height, bin_w, bin_h; RtwBinsDev* d_bins; const float* d_dx; const float* d_dy;
                     std::vector<uint32_t> weight;           // per bin: leaves listed, over all shapes (1000+ for a shape without bins)
-                    std::vector<JobTable> jobs; };          // job tables per (task partition, sub-sample count) rendered so far
+                    std::vector<JobTable> jobs;             // job tables per (task partition, sub-sample count) rendered so far
+                    std::vector<GroupTable> gtables; };
     std::vector<BinSet> bin_sets;
 };
 
@@ -215,6 +233,10 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipHostMalloc((void**)&c->h_pass, 64, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&c->d_pass, 64));
     HIP_TRY(hipEventCreateWithFlags(&c->counters_event, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&c->h_gcounters, 256, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&c->gcounters_event, hipEventDisableTiming));
+    for (int i = 0; i < 64; i++) c->h_gcounters[i] = 0;
+    for (int r = 0; r < 32; r++) c->known_ground[r] = -1;
     for (int i = 0; i < 64; i++) c->h_counters[i] = 0;
     for (int r = 0; r < 32; r++) c->known_rounds[r] = -1;
     HIP_TRY(hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)));
@@ -237,6 +259,9 @@ int rtw_context_destroy(rtw_context* ctx)
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
+    if (ctx->d_group_ws) (void)hipFree(ctx->d_group_ws);
+    if (ctx->h_gcounters) (void)hipHostFree(ctx->h_gcounters);
+    if (ctx->gcounters_event) (void)hipEventDestroy(ctx->gcounters_event);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->counters_event) (void)hipEventDestroy(ctx->counters_event);
     for (int i = 0; i < 4; i++) if (ctx->timing_events[i]) (void)hipEventDestroy(ctx->timing_events[i]);
@@ -257,8 +282,14 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
 {
     if (!ctx || !name) return fail(RTW_ERR_INVALID, "null argument");
     if (std::strcmp(name, "pipeline") == 0) {
-        if (value < 0 || value > 3) return fail(RTW_ERR_INVALID, "pipeline must be 0, 1, 2 or 3");
+        if (value < 0 || value > 4) return fail(RTW_ERR_INVALID, "pipeline must be 0 .. 4");
         ctx->pipeline = value;
+        return RTW_OK;
+    }
+    if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
+    if (std::strcmp(name, "group_max") == 0) {
+        if (value < 1 || value > 64 || (value & (value - 1)) != 0) return fail(RTW_ERR_INVALID, "group_max must be a power of two in 1..64");
+        ctx->group_max = value;
         return RTW_OK;
     }
     if (std::strcmp(name, "trace_block") == 0) { ctx->trace_block = (value == 64 || value == 128) ? value : 256; return RTW_OK; }
@@ -316,6 +347,12 @@ int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3])
     HIP_TRY(hipEventSynchronize(ctx->timing_events[3]));
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out3[i], ctx->timing_events[i], ctx->timing_events[i + 1]));
     return RTW_OK;
+}
+
+int rtw_last_pass_pipeline(rtw_context* ctx)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    return ctx->last_pipeline;
 }
 
 int rtw_context_synchronize(rtw_context* ctx)
@@ -844,7 +881,7 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
     for (rtw_scene::BinSet& b : scene->bin_sets)
         if (b.width == width && b.height == height && b.bin_w == bin_w && b.bin_h == bin_h) { *out = &b; return RTW_OK; }
     std::vector<RtwBinsDev> h(scene->meshes.size());
-    const size_t n_bins = (size_t)(width / bin_w) * (size_t)(height / bin_h);
+    const size_t n_bins = (size_t)((width + bin_w - 1) / bin_w) * (size_t)((height + bin_h - 1) / bin_h);
     std::vector<uint32_t> weight(n_bins, 0u);
     for (size_t s = 0; s < scene->meshes.size(); s++) {
         std::vector<uint32_t> off, ent;
@@ -949,6 +986,184 @@ static bool choose_tiles(RtwRenderParams& p)
     return false;
 }
 
+// ---- pass-batched pipeline (pipeline 4) -----------------------------------------------------------------------------------
+// Tile mapping of a group launch: 16 x 4-pixel tiles (32 x 2 / 64 x 1 when a rank's task rows do not divide by 4), one wave each, aligned to
+// the screen's bin grid.  Frames that do not tile get partial tiles at the right / bottom edge, a pixel range that does not start / end on
+// a tile row gets dead lanes (range_begin / range_end).
+static bool choose_group_tiles(RtwRenderParams& p, int range_begin, int range_end)
+{
+    const int W = p.width, H = p.height;
+    if (W <= 0 || H <= 0) return false;
+    int th = 4;
+    if (p.world > 1) { th = p.task_rows % 4 == 0 ? 4 : (p.task_rows % 2 == 0 ? 2 : 1); }
+    const int tw = 64 / th;
+    long long vrows; int row0 = 0;
+    if (p.world <= 1) {
+        const int r_first = range_begin / W, r_last = range_end / W;
+        row0 = (r_first / th) * th;
+        vrows = (long long)r_last - row0 + 1;
+    } else {
+        vrows = p.count / W;            // the rank's virtual rows (whole tasks; rows past the frame's bottom are dead)
+    }
+    const long long bands = (vrows + th - 1) / th;
+    const long long tiles_per_row = (W + tw - 1) / tw;
+    const long long count = bands * tiles_per_row * 64;
+    if (count > INT32_MAX || bands * tiles_per_row >= (1 << 24)) return false;
+    p.tile_w = tw; p.tile_h = th; p.tiles_per_row = (int)tiles_per_row;
+    p.tile_shift = tw == 16 ? 4 : (tw == 32 ? 5 : 6);
+    p.row0 = row0; p.nrows = (int)vrows;
+    p.count = (int)count;
+    return true;
+}
+
+// busy / sky tile lists and the primary kernel's job list of one (task partition, sub-sample count), full frames only
+static int scene_group_table(rtw_scene* scene, rtw_scene::BinSet& bs, const RtwRenderParams& p, int spp, const rtw_scene::GroupTable** out)
+{
+    *out = nullptr;
+    const bool linear = p.world <= 1;
+    const int key_rows = linear ? 0 : p.task_rows, key_rank = linear ? 0 : p.rank, key_world = linear ? 1 : p.world;
+    for (const rtw_scene::GroupTable& t : bs.gtables)
+        if (t.task_rows == key_rows && t.rank == key_rank && t.world == key_world && t.spp == spp) { *out = &t; return RTW_OK; }
+    const int n_tiles = p.count >> 6;
+    const int tiles_per_row = p.tiles_per_row;
+    std::vector<uint32_t> w((size_t)n_tiles, 0u);
+    std::vector<uint8_t> dead((size_t)n_tiles, 0);
+    for (int wt = 0; wt < n_tiles; wt++) {
+        const int band = wt / tiles_per_row, tx = wt - band * tiles_per_row;
+        const int vr = band * p.tile_h;
+        int y;
+        if (linear) y = p.row0 + vr;
+        else { const int j = vr / p.task_rows, r = vr - j * p.task_rows; y = (j * p.world + p.rank) * p.task_rows + r; }
+        if (vr >= p.nrows || y >= p.height) { dead[(size_t)wt] = 1; continue; }
+        w[(size_t)wt] = bs.weight[(size_t)(y / p.tile_h) * (size_t)tiles_per_row + (size_t)tx];
+    }
+    std::vector<uint32_t> busy, sky, jobs;
+    for (int wt = 0; wt < n_tiles; wt++) {
+        if (dead[(size_t)wt]) continue;
+        (w[(size_t)wt] > 0u ? busy : sky).push_back((uint32_t)wt);
+    }
+    std::stable_sort(busy.begin(), busy.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+    for (size_t b = 0; b < busy.size(); b++) {
+        // with several sub-samples a tile with a long list is one job PER sub-sample (its waves share the list walk)
+        if (spp > 1 && w[busy[b]] >= 40u) for (int i = 0; i < spp; i++) jobs.push_back((uint32_t)b | ((uint32_t)(i + 1) << 24));
+        else jobs.push_back((uint32_t)b);
+    }
+    rtw_scene::GroupTable gt; gt.task_rows = key_rows; gt.rank = key_rank; gt.world = key_world; gt.spp = spp;
+    gt.d_busy = gt.d_sky = gt.d_jobs = nullptr;
+    int rc;
+    if ((rc = upload(scene, busy, &gt.d_busy)) != RTW_OK) return rc;
+    if ((rc = upload(scene, sky, &gt.d_sky)) != RTW_OK) return rc;
+    if ((rc = upload(scene, jobs, &gt.d_jobs)) != RTW_OK) return rc;
+    gt.n_busy = (int)busy.size(); gt.n_sky = (int)sky.size(); gt.n_jobs = (int)jobs.size();
+    bs.gtables.push_back(gt);
+    *out = &bs.gtables.back();
+    return RTW_OK;
+}
+
+static int ensure_group_workspace(rtw_context* cx, size_t bytes)
+{
+    if (bytes <= cx->group_ws_bytes) return RTW_OK;
+    HIP_TRY(hipStreamSynchronize(cx->stream));
+    if (cx->aux_stream) HIP_TRY(hipStreamSynchronize(cx->aux_stream));
+    if (cx->d_group_ws) { (void)hipFree(cx->d_group_ws); cx->d_group_ws = nullptr; cx->group_ws_bytes = 0; }
+    cx->group_clean = false;
+    HIP_TRY(hipMalloc(&cx->d_group_ws, bytes));
+    cx->group_ws_bytes = bytes;
+    return RTW_OK;
+}
+
+static int check_render_args(const rtw_scene* scene, const rtw_framebuffer* fb, int max_bounce, int pass_index, int sub_samples)
+{
+    if (fb->ctx != scene->ctx) return fail(RTW_ERR_INVALID, "scene and framebuffer belong to different contexts");
+    if (max_bounce < 0 || max_bounce > RTW_MAX_BOUNCE) return fail(RTW_ERR_LIMIT, "max_bounce out of range");
+    if (sub_samples < 1 || sub_samples > 4) return fail(RTW_ERR_INVALID, "sub_samples must be 1..4");
+    if (pass_index < 0) return fail(RTW_ERR_INVALID, "pass_index must be >= 0");
+    return RTW_OK;
+}
+
+// Can this scene / context go through the pass-batched pipeline?  (The reference-order walk used for work counters, traversal 0,
+// and the "packets 0" comparison mode stay with the older kernels.)
+static bool group_pipeline_ok(const rtw_scene* scene)
+{
+    return scene->ctx->pipeline == 4 && scene->traversal != 0 && scene->ctx->packets != 0;
+}
+
+// how many of the `remaining` passes the next group takes: enough for about group_paths paths per launch, a power of two of slots
+static int group_passes(const rtw_context* cx, long long paths_per_pass, int remaining, int max_bounce, bool carry)
+{
+    long long k = 1;
+    while (k < cx->group_max && k * paths_per_pass < cx->group_paths) k <<= 1;
+    // memory: at most ~6 GiB of workspace and 2^30 slots
+    for (;;) {
+        const size_t bytes = rtw::group_workspace_bytes((size_t)(paths_per_pass * k), max_bounce, carry, nullptr);
+        if (k == 1 || (bytes <= ((size_t)6 << 30) && paths_per_pass * k < ((long long)1 << 30))) break;
+        k >>= 1;
+    }
+    return (int)(k < remaining ? k : remaining);
+}
+
+// One group: passes first_pass .. first_pass + n_passes - 1 over the pixels begin .. end of this rank's share of the frame.
+// ranged: a pixel range (rtw_render_range), else the whole frame / the rank's tasks.  batch_pos as rtw_context::batch_pos.
+static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p, bool ranged, int range_begin, int range_end,
+                        int max_bounce, int use_base_color, int first_pass, int n_passes, int sub_samples, uint32_t seed)
+{
+    rtw_context* cx = scene->ctx;
+    p.width = fb->width; p.height = fb->height;
+    p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = first_pass; p.sub_samples = sub_samples; p.seed = seed;
+    if (!choose_group_tiles(p, range_begin, range_end)) return fail(RTW_ERR_LIMIT, "frame too large for the tile mapping");
+    rtw_scene::BinSet* bs = nullptr;
+    int rc = scene_bins(scene, p.width, p.height, p.tile_w, p.tile_h, &bs); if (rc != RTW_OK) return rc;
+    p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
+    RtwGroupParams g; std::memset(&g, 0, sizeof g);
+    g.first_pass = first_pass; g.n_passes = n_passes;
+    int kshift = 0; while ((1 << kshift) < n_passes) kshift++;
+    g.kshift = kshift;
+    g.range_begin = range_begin; g.range_end = range_end; g.first_tile = 0;
+    if (ranged) {           // every tile of the range is a job; the primary kernel finds out which see the sky only
+        g.n_busy = p.count >> 6; g.n_sky = 0; g.n_jobs = g.n_busy;
+        g.busy_tiles = nullptr; g.sky_tiles = nullptr; g.jobs = nullptr;
+    } else {
+        const rtw_scene::GroupTable* gt = nullptr;
+        rc = scene_group_table(scene, *bs, p, sub_samples, &gt); if (rc != RTW_OK) return rc;
+        g.n_busy = gt->n_busy; g.n_sky = gt->n_sky; g.n_jobs = gt->n_jobs;
+        g.busy_tiles = gt->d_busy; g.sky_tiles = gt->d_sky; g.jobs = gt->d_jobs;
+    }
+    g.rp = p;
+    const bool carry = scene->texture_carry;
+    const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
+    if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");
+    rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
+    rtw::GroupTuning tune;
+    tune.capacity = capacity;
+    tune.aux_stream = cx->sky_split ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
+    tune.do_fork = cx->batch_pos == 0 || cx->batch_pos == 1 || !cx->aux_unjoined;
+    tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
+    tune.gamma_thr = cx->d_gamma;
+    tune.has_analytic = scene->has_analytic; tune.carry = carry;
+    tune.counters_clean = cx->group_clean;
+    tune.cu_count = cx->cu_count;
+    tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
+    // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
+    rtw_context::GroupKey key; key.scene = scene; key.capacity = (long long)capacity; key.max_bounce = max_bounce; key.preview = p.preview; key.n_passes = n_passes;
+    if (cx->gcounters_pending && hipEventQuery(cx->gcounters_event) == hipSuccess) {
+        cx->known_gkey = cx->gcounters_key; cx->gcounters_pending = false;
+        for (int r = 0; r < 32; r++) cx->known_ground[r] = (int)cx->h_gcounters[r];
+    }
+    for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_gkey == key) ? cx->known_ground[r] : -1;
+    cx->group_clean = false;
+    const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws, g, tune, cx->stats_enabled, cx->stream);
+    if (e != hipSuccess) return hip_fail(e, "group launch");
+    cx->group_clean = true;
+    cx->last_pipeline = 4;
+    if (!cx->gcounters_pending && g.n_busy > 0 && (!(cx->known_gkey == key) || (cx->hint_tick++ % cx->hint_period) == 0)) {
+        if (hipMemcpyAsync(cx->h_gcounters, (char*)cx->d_group_ws + 256, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
+            hipEventRecord(cx->gcounters_event, cx->stream) == hipSuccess) {
+            cx->gcounters_pending = true; cx->gcounters_key = key;
+        }
+    }
+    return RTW_OK;
+}
+
 // ---- the hot path -------------------------------------------------------------------------------------------
 static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams& p, int max_bounce, int use_base_color,
                          int pass_index, int sub_samples, uint32_t seed, bool capturing = false, bool* used_bins_pipeline = nullptr)
@@ -961,7 +1176,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
     p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
     hipError_t e;
     // the bins + wave pipeline needs whole rows, the flat hierarchy (traversal != 0) and a frame that tiles; else pipeline 2
-    int pipeline = scene->ctx->pipeline;
+    int pipeline = scene->ctx->pipeline > 3 ? 3 : scene->ctx->pipeline;
     // spheres / planes / capsules are built into the bins + wave pipeline and the single kernel; the two older pipelines
     // (options 1 and 2) then run as the single kernel, and so does a scene whose analytic hits can inherit a texel
     const int fallback = scene->has_analytic ? 0 : 2;
@@ -1084,6 +1299,7 @@ static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams&
         e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
     }
     if (e != hipSuccess) return hip_fail(e, "render_kernel launch");
+    scene->ctx->last_pipeline = pipeline;
     return RTW_OK;
 }
 
@@ -1097,6 +1313,11 @@ int rtw_render_range(rtw_scene* scene, rtw_framebuffer* fb, int begin, int end, 
     RtwRenderParams p; std::memset(&p, 0, sizeof p);
     p.begin = begin; p.count = end >= begin ? end - begin + 1 : 0;      // an empty range renders nothing, like the reference loop
     p.task_rows = 0; p.rank = 0; p.world = 1;
+    if (group_pipeline_ok(scene)) {
+        rc = check_render_args(scene, fb, max_bounce, pass_index, sub_samples); if (rc != RTW_OK) return rc;
+        if (p.count == 0) return RTW_OK;
+        return render_group(scene, fb, p, !(begin == 0 && end == npix - 1), begin, end, max_bounce, use_base_color, pass_index, 1, sub_samples, seed);
+    }
     return render_common(scene, fb, p, max_bounce, use_base_color, pass_index, sub_samples, seed);
 }
 
@@ -1117,6 +1338,11 @@ int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int r
         if (cnt > INT32_MAX) return fail(RTW_ERR_LIMIT, "too many work items");
         p.count = (int)cnt;
     }
+    if (group_pipeline_ok(scene)) {
+        rc = check_render_args(scene, fb, max_bounce, pass_index, sub_samples); if (rc != RTW_OK) return rc;
+        if (p.count == 0) return RTW_OK;
+        return render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, pass_index, 1, sub_samples, seed);
+    }
     return render_common(scene, fb, p, max_bounce, use_base_color, pass_index, sub_samples, seed);
 }
 
@@ -1131,6 +1357,43 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
     if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
     if (n_passes < 0 || first_pass < 0) return fail(RTW_ERR_INVALID, "bad pass range");
     rtw_context* cx = scene->ctx;
+    if (group_pipeline_ok(scene)) {
+        // groups of passes share one set of launches (rtw_group_kernels.h); the groups of this call fork the second stream once and join it once
+        if (task_rows < 1 || world < 1 || rank < 0 || rank >= world) return fail(RTW_ERR_INVALID, "bad task partition");
+        rc = check_render_args(scene, fb, max_bounce, first_pass, sub_samples); if (rc != RTW_OK) return rc;
+        RtwRenderParams p; std::memset(&p, 0, sizeof p);
+        const int n_tasks = (fb->height + task_rows - 1) / task_rows;
+        const int mine = n_tasks > rank ? (n_tasks - rank + world - 1) / world : 0;
+        p.begin = 0; p.task_rows = task_rows; p.rank = rank; p.world = world;
+        const int64_t cnt = world == 1 ? (int64_t)fb->width * fb->height : (int64_t)mine * task_rows * fb->width;
+        if (cnt > INT32_MAX) return fail(RTW_ERR_LIMIT, "too many work items");
+        p.count = (int)cnt;
+        if (p.count == 0) return RTW_OK;
+        // paths per pass: the busy tiles' pixels x sub-samples (known once the tile lists exist; the whole share until then)
+        long long per_pass = (long long)p.count * sub_samples;
+        {
+            RtwRenderParams t = p; t.width = fb->width; t.height = fb->height;
+            rtw_scene::BinSet* bs = nullptr; const rtw_scene::GroupTable* gt = nullptr;
+            if (choose_group_tiles(t, 0, fb->width * fb->height - 1) && scene_bins(scene, t.width, t.height, t.tile_w, t.tile_h, &bs) == RTW_OK &&
+                scene_group_table(scene, *bs, t, sub_samples, &gt) == RTW_OK && gt) per_pass = (long long)gt->n_busy * 64 * sub_samples;
+        }
+        int done = 0;
+        while (done < n_passes) {
+            const int k = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, n_passes - done, max_bounce, scene->texture_carry);
+            const bool first = done == 0, last = done + k >= n_passes;
+            cx->batch_pos = (first && last) ? 0 : (first ? 1 : (last ? 3 : 2));
+            rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);
+            cx->batch_pos = 0;
+            if (cx->aux_unjoined && (rc != RTW_OK || last)) {     // the run ends here (an error, or a last group that launched no sky kernel)
+                (void)hipEventRecord(cx->join_event, cx->aux_stream);
+                (void)hipStreamWaitEvent(cx->stream, cx->join_event, 0);
+                cx->aux_unjoined = false;
+            }
+            if (rc != RTW_OK) return rc;
+            done += k;
+        }
+        return RTW_OK;
+    }
     rtw_context::PassGraph& g = cx->pass_graph;
     for (int i = 0; i < n_passes; i++) {
         const int pass = first_pass + i;
@@ -1157,7 +1420,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
             cx->aux_unjoined = false;
         }
         if (rc != RTW_OK) return rc;
-        if (!cx->use_graph || cx->stats_enabled || cx->kernel_timing || cx->pipeline != 3 || i + 1 >= n_passes) continue;
+        if (!cx->use_graph || cx->stats_enabled || cx->kernel_timing || cx->pipeline < 3 || i + 1 >= n_passes) continue;
         // wait for this pass's queue lengths, then capture the next pass
         if (cx->counters_pending) { HIP_TRY(hipEventSynchronize(cx->counters_event)); }
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }

@@ -469,8 +469,8 @@ void build_flat(HostMesh& m)
 bool build_bins(const HostMesh& m, int width, int height, int bin_w, int bin_h, std::vector<uint32_t>& off, std::vector<uint32_t>& ent)
 {
     off.clear(); ent.clear();
-    if (width <= 0 || height <= 0 || bin_w <= 0 || bin_h <= 0 || width % bin_w != 0 || height % bin_h != 0) return false;
-    const int bx = width / bin_w, by = height / bin_h;
+    if (width <= 0 || height <= 0 || bin_w <= 0 || bin_h <= 0) return false;
+    const int bx = (width + bin_w - 1) / bin_w, by = (height + bin_h - 1) / bin_h;      // the bins at the right / bottom edge may be partial
     const double cx = (double)(width / 2), cy = (double)(height / 2), H = (double)height;
     // A sub-sample looks through a point up to 1.25 / (4 W) off its pixel centre in dx and dy (Src/RayTracerProgram.cpp:147-162), i.e.
     // 1.25 H / (2 W) PIXELS (a pixel is 1 / (2 H) wide in those units): under half a pixel for landscape frames, several pixels for tall
