@@ -69,9 +69,14 @@ struct GroupTuning {
     bool counters_clean = false;   // the list counters are zero (left so by the previous group)
     int round_hint[32];            // list lengths of the previous group per round (-1 = unknown): they size the launches
     int cu_count = 256;
+    bool single_mesh = false, persist = true; // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
+    int wave_below = 0;                      // a trace round whose list (previous group's length) is shorter than this runs a wave per ray
+    bool staged_all = false;                 // ... and that is the shape's whole tree
+    int staged_shape = -1, staged_top = 0;   // the trace blocks stage the first staged_top tnodes records of this shape in LDS (-1: nothing staged)
     hipEvent_t* timing = nullptr;  // null, or 4 events: before the primary kernel, after it, after the bounce rounds, after resolve
 };
 int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwGroupParams& g, const GroupTuning& tune, bool stats, hipStream_t stream);
+#define RTW_TNODES_TOP_BUDGET 3072 // records (32 B each) of a tree's upper levels a block of the ray-per-lane trace kernel stages in LDS: 96 KiB
 #define RTW_LDS_WIDE_BUDGET 160   // 16-wide nodes (448 B each) that may be staged in LDS: 70 KiB -> two 256-thread blocks per CU
 #define RTW_LDS_QUAD_BUDGET 1024  // quads (128 B each) that may be staged in LDS beside the per-quartet trails and lists
 int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream);

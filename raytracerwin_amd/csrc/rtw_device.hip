@@ -2307,14 +2307,68 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
         if (!p.preview) {
             for (int r = 1; r < p.max_bounce; r++) {       // the primary kernel was shade(0); trace(r - 1) then shade(r)
                 const unsigned tb = blocks_for(r - 1);
+#define RTW_LAUNCH_GT(ST, AN_, NT_, CAP_, STG, BLOCKS, DYN)                                                                                      \
+                do {                                                                                                                            \
+                    if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_kernel<ST, AN_, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                    hipLaunchKernelGGL((gtrace_kernel<ST, AN_, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.staged_shape); \
+                } while (0)
+#define RTW_LAUNCH_GT4(NT_, CAP_, STG, BLOCKS, DYN)                                                                                             \
+                do {                                                                                                                            \
+                    if (tune.has_analytic) { if (stats) RTW_LAUNCH_GT(true, true, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, true, NT_, CAP_, STG, BLOCKS, DYN); } \
+                    else { if (stats) RTW_LAUNCH_GT(true, false, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, false, NT_, CAP_, STG, BLOCKS, DYN); } \
+                } while (0)
+                if (!tune.carry && tune.round_hint[r - 1] >= 0 && tune.round_hint[r - 1] < tune.wave_below) {
+                    // a short list: a wave per ray (128-thread blocks, a wave takes rays in turn)
+                    constexpr int NTV = 128;
+                    long long blocks = ((long long)tune.round_hint[r - 1] + tune.round_hint[r - 1] / 4 + 64 + NTV / 64 - 1) / (NTV / 64);
+                    const long long cap = (long long)tune.cu_count * 64;
+                    if (blocks < 1) blocks = 1;
+                    if (blocks > cap) blocks = cap;
+                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
+                    if (tune.has_analytic) {
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
+                    } else {
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
+                    }
+                } else if (tune.single_mesh && tune.persist) {
+                    // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
+#define RTW_LAUNCH_GP(NT_, CAP_, STG, BLOCKS, DYN)                                                                                               \
+                    do {                                                                                                                        \
+                        if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1); } \
+                        else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1); } \
+                    } while (0)
+                    if (tune.staged_shape == 0 && tune.staged_top > 0) {
+                        unsigned sbl = (tb + 3) / 4;
+                        if (sbl > (unsigned)tune.cu_count) sbl = (unsigned)tune.cu_count;
+                        const size_t dyn = (size_t)RTW_GT_CAP_STAGED * 1024 * 4 + (size_t)tune.staged_top * 32;
+                        if (tune.staged_all) RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 2, sbl, dyn);
+                        else RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 1, sbl, dyn);
+                    } else {
+                        unsigned bl = tb;
+                        if (bl > (unsigned)tune.cu_count * 8u) bl = (unsigned)tune.cu_count * 8u;
+                        const size_t dyn = (size_t)RTW_GT_CAP * 256 * 4;
+                        RTW_LAUNCH_GP(256, RTW_GT_CAP, 0, bl, dyn);
+                    }
+#undef RTW_LAUNCH_GP
+                } else if (tune.staged_shape >= 0 && tune.staged_top > 0) {
+                    const unsigned sbl = (tb + 3) / 4;          // 1024-thread blocks
+                    const size_t dyn = (size_t)RTW_GT_CAP_STAGED * 1024 * 4 + (size_t)tune.staged_top * 32;
+                    if (tune.staged_all) RTW_LAUNCH_GT4(1024, RTW_GT_CAP_STAGED, 2, sbl, dyn);
+                    else RTW_LAUNCH_GT4(1024, RTW_GT_CAP_STAGED, 1, sbl, dyn);
+                } else {
+                    const size_t dyn = (size_t)RTW_GT_CAP * 256 * 4;
+                    RTW_LAUNCH_GT4(256, RTW_GT_CAP, 0, tb, dyn);
+                }
+#undef RTW_LAUNCH_GT4
+#undef RTW_LAUNCH_GT
                 if (tune.has_analytic) {
-                    if (stats) hipLaunchKernelGGL((gtrace_kernel<true, true>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
-                    else hipLaunchKernelGGL((gtrace_kernel<false, true>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
                     if (stats) hipLaunchKernelGGL((gshade_kernel<true, true>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
                     else hipLaunchKernelGGL((gshade_kernel<false, true>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
                 } else {
-                    if (stats) hipLaunchKernelGGL((gtrace_kernel<true, false>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
-                    else hipLaunchKernelGGL((gtrace_kernel<false, false>), dim3(tb), dim3(256), 0, stream, sc, gb, r - 1);
                     if (stats) hipLaunchKernelGGL((gshade_kernel<true, false>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
                     else hipLaunchKernelGGL((gshade_kernel<false, false>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
                 }

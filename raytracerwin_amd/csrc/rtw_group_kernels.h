@@ -22,7 +22,13 @@
 //
 // Every float operation is the one the other pipelines execute, in the same order; the tests compare them bit for bit.
 
-#define RTW_GT_CAP 16           // candidate leaves a lane of gtrace_kernel notes before the wave runs its triangle tests
+#ifdef RTW_TIMING
+#define RTW_GT_COUNT(x) (x)++
+#else
+#define RTW_GT_COUNT(x) (void)0
+#endif
+#define RTW_GT_CAP 16           // candidate leaves a lane of gtrace_kernel notes before the wave runs its triangle tests (256-thread blocks, nothing staged)
+#define RTW_GT_CAP_STAGED 8     // ... in the 1024-thread blocks that stage a tree's upper levels in LDS
 
 struct GroupBufs {
     float4* __restrict__ rad;       // [capacity]      radiance of a finished path
@@ -356,69 +362,119 @@ __device__ __forceinline__ LaneRay lane_ray_of(const Ray& r)
 }
 
 // KdNode::TestRayIntersection (Src/KdTree.cpp:128-195) of every lane's own ray on one mesh: the preorder walk of tree_walk with the
-// triangle tests postponed.  `go`: this lane's ray passed the shape's culling box.  On return cur / pos / leaf hold what the
-// reference's recursion leaves in TestRay.Distance / *OutResult / *TriangleIndex.
-template <bool STATS>
-__device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* __restrict__ cand, const Ray& r, const LaneRay& q, bool go, bool prune,
-                                               float& cur, f3& pos, int& leaf_out, Counters& ct)
+// triangle tests postponed, over the explicit-link records (RtwShapeDev::tnodes).  `go`: this lane's ray passed the shape's culling
+// box.  `lnodes`: the first `ltop` records, staged in LDS by the block (ALLDS: that is the whole tree, the walk never leaves LDS).
+// `cand`: the block's candidate lists, entry j of thread t at [j * NT + t], CAP entries per lane.  On return cur / pos / leaf hold
+// what the reference's recursion leaves in TestRay.Distance / *OutResult / *TriangleIndex.
+//
+// The box test (RRay::TestIntersectionWithAabb, Src/RRay.cpp:89-136) of a tame ray: (pair - origin) * reciprocal per axis as packed
+// operations, v_min / v_max (no NaN, no skipped axis: the same values as the reference's ternaries), then the conservative segment
+// clip.  A wave that holds a ray that is not tame takes the loop that also evaluates the test as written.
+template <bool STATS, int NT, int CAP, bool ALLDS>
+__device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* __restrict__ cand, const float4* __restrict__ lnodes, int ltop,
+                                               const Ray& r, const LaneRay& q, bool go, bool prune, float& cur, f3& pos, int& leaf_out, Counters& ct,
+                                               int& dbg_walk, int& dbg_tri, int& dbg_flush)
 {
-    const float4* nd4 = reinterpret_cast<const float4*>(sh.nodes);
+    const float4* nd4 = reinterpret_cast<const float4*>(sh.tnodes);
     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
     const int n_nodes = sh.n_nodes;
     const int tid = (int)threadIdx.x;
     const bool any_untame = __ballot(go && !q.tame) != 0ull;
+    const rtw_v2f ox = { q.o.x, q.o.x }, oy = { q.o.y, q.o.y }, oz = { q.o.z, q.o.z };
+    const rtw_v2f vx = { q.ix, q.ix }, vy = { q.iy, q.iy }, vz = { q.iz, q.iz };
+    const float neg_eps = prune ? -q.eps_t : -INFINITY;
     bool any = false;
     int i = go ? 0 : n_nodes;
     int ncand = 0;
     for (;;) {
-        const bool walking = i < n_nodes;
-        const bool more = __ballot(walking) != 0ull;
-        if (walking) {
-            const float4 lo = gld4(nd4, 2 * (size_t)i), hi = gld4(nd4, 2 * (size_t)i + 1);
-            const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
-            const float x1 = (lo.x - q.o.x) * q.ix, x2 = (hi.x - q.o.x) * q.ix;
-            const float y1 = (lo.y - q.o.y) * q.iy, y2 = (hi.y - q.o.y) * q.iy;
-            const float z1 = (lo.z - q.o.z) * q.iz, z2 = (hi.z - q.o.z) * q.iz;
-            const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
-            const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-            bool hit = tmax > tmin;
-            if (prune) hit = hit && !(tmin > cur + (q.eps_t + 1.0e-4f * cur)) && !(tmax < -q.eps_t);
-            if (any_untame) {            // wave-uniform, rare
-                float emin = -FLT_MAX, emax = FLT_MAX;
-                if (!q.skx) { emin = ref_max(emin, ref_min(x1, x2)); emax = ref_min(emax, ref_max(x1, x2)); }
-                if (!q.sky) { emin = ref_max(emin, ref_min(y1, y2)); emax = ref_min(emax, ref_max(y1, y2)); }
-                if (!q.skz) { emin = ref_max(emin, ref_min(z1, z2)); emax = ref_min(emax, ref_max(z1, z2)); }
-                if (!q.tame) hit = emax > emin;
+        const float far_t = prune ? cur + (q.eps_t + 1.0e-4f * cur) : INFINITY;       // the segment only changes in the triangle phase below
+        // ---- walk: every lane steps through its own records until all are done or some lane's list is full ----
+        if (!any_untame) {
+            for (;;) {
+                const bool walking = i < n_nodes;
+                if (__ballot(walking) == 0ull) break;
+                RTW_GT_COUNT(dbg_walk);
+                if (walking) {
+                    float4 a, b;
+                    if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
+                    else { a = gld4(nd4, 2 * (size_t)i); b = gld4(nd4, 2 * (size_t)i + 1); }
+                    const int skip = __float_as_int(b.z), link = __float_as_int(b.w);
+                    const rtw_v2f bx = { a.x, a.y }, by = { a.z, a.w }, bz = { b.x, b.y };
+                    const rtw_v2f tx = (bx - ox) * vx, ty = (by - oy) * vy, tz = (bz - oz) * vz;
+                    const float tmin = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+                    const float tmax = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+                    const bool hit = (tmax > tmin) & !(tmin > far_t) & !(tmax < neg_eps);
+                    const bool leaf = link >= 0;
+                    if (STATS) ct.boxes++;
+                    if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
+                    i = (hit & !leaf) ? ~link : skip;
+                }
+                if (__ballot(ncand == CAP) != 0ull) break;
             }
-            if (STATS) ct.boxes++;
-            if (hit && leaf >= 0) { lstu(cand, ncand * 256 + tid, (uint32_t)leaf); ncand++; }
-            i = (hit && leaf < 0) ? i + 1 : skip;
+        } else {
+            for (;;) {
+                const bool walking = i < n_nodes;
+                if (__ballot(walking) == 0ull) break;
+                RTW_GT_COUNT(dbg_walk);
+                if (walking) {
+                    float4 a, b;
+                    if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
+                    else { a = gld4(nd4, 2 * (size_t)i); b = gld4(nd4, 2 * (size_t)i + 1); }
+                    const int skip = __float_as_int(b.z), link = __float_as_int(b.w);
+                    const float x1 = (a.x - q.o.x) * q.ix, x2 = (a.y - q.o.x) * q.ix;
+                    const float y1 = (a.z - q.o.y) * q.iy, y2 = (a.w - q.o.y) * q.iy;
+                    const float z1 = (b.x - q.o.z) * q.iz, z2 = (b.y - q.o.z) * q.iz;
+                    const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                    const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                    bool hit = (tmax > tmin) & !(tmin > far_t) & !(tmax < neg_eps);
+                    float emin = -FLT_MAX, emax = FLT_MAX;      // RRay::TestIntersectionWithAabb as written, for the lanes that need it
+                    if (!q.skx) { emin = ref_max(emin, ref_min(x1, x2)); emax = ref_min(emax, ref_max(x1, x2)); }
+                    if (!q.sky) { emin = ref_max(emin, ref_min(y1, y2)); emax = ref_min(emax, ref_max(y1, y2)); }
+                    if (!q.skz) { emin = ref_max(emin, ref_min(z1, z2)); emax = ref_min(emax, ref_max(z1, z2)); }
+                    if (!q.tame) hit = emax > emin;
+                    const bool leaf = link >= 0;
+                    if (STATS) ct.boxes++;
+                    if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
+                    i = (hit & !leaf) ? ~link : skip;
+                }
+                if (__ballot(ncand == CAP) != 0ull) break;
+            }
         }
-        // the noted leaves' triangle tests: when some lane's list is full, and at the end of the walk
-        if (more && __ballot(ncand == RTW_GT_CAP) == 0ull) continue;
-        for (int j = 0; ; j++) {
-            const bool mine = j < ncand;
-            if (__ballot(mine) == 0ull) break;
-            if (mine) {
-                const int leaf = (int)lldu(cand, j * 256 + tid);
-                const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
-                if (STATS) ct.tris++;
-                f3 cp; float dist;
-                if (triangle_test(r, cur, a, b, c, d.x, cp, dist)) { cur = dist; pos = cp; leaf_out = leaf; any = true; }
+        // ---- the noted leaves' triangle tests, all lanes together, each lane through its own list in order; the next record is
+        // fetched while the current one is tested ----
+        {
+            bool mine = 0 < ncand;
+            int leaf = mine ? (int)lldu(cand, tid) : 0;
+            float4 ta = gld4(tr4, 4 * (size_t)leaf), tb = gld4(tr4, 4 * (size_t)leaf + 1), tc = gld4(tr4, 4 * (size_t)leaf + 2);
+            float td = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)leaf + 12);
+            RTW_GT_COUNT(dbg_flush);
+            for (int j = 0; __ballot(mine) != 0ull; j++) {
+                RTW_GT_COUNT(dbg_tri);
+                const bool nmine = j + 1 < ncand;
+                const int nleaf = nmine ? (int)lldu(cand, (j + 1) * NT + tid) : 0;
+                const float4 na = gld4(tr4, 4 * (size_t)nleaf), nb = gld4(tr4, 4 * (size_t)nleaf + 1), nc = gld4(tr4, 4 * (size_t)nleaf + 2);
+                const float nd = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)nleaf + 12);
+                if (mine) {
+                    if (STATS) ct.tris++;
+                    f3 cp; float dist;
+                    if (triangle_test(r, cur, ta, tb, tc, td, cp, dist)) { cur = dist; pos = cp; leaf_out = leaf; any = true; }
+                }
+                mine = nmine; leaf = nleaf; ta = na; tb = nb; tc = nc; td = nd;
             }
         }
         ncand = 0;
-        if (!more) break;
+        if (__ballot(i < n_nodes) == 0ull) break;
     }
     return any;
 }
 
-// FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) of every lane's own ray, without the shading tail (only the record of
-// the last shape that hit is read afterwards; carry_* = the mesh hit whose sampled colour a later analytic hit keeps).
-template <bool STATS, bool AN>
-__device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ cand, const Ray& ray, bool have,
+// staged_shape: the shape whose upper tree levels the block holds in LDS (lnodes, ltop), or -1
+template <bool STATS, bool AN, int NT, int CAP, bool ALLDS>
+__device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ cand, const float4* __restrict__ lnodes, int ltop, int staged_shape,
+                                                       const Ray& ray, bool have,
                                                        int& hit_shape, int& hit_slot, f3& hit_pos, float& seg,
-                                                       int& carry_shape, int& carry_slot, f3& carry_pos, float& carry_dist, Counters& ct)
+                                                       int& carry_shape, int& carry_slot, f3& carry_pos, float& carry_dist, Counters& ct,
+                                                       int& dbg_walk, int& dbg_tri, int& dbg_flush)
 {
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
@@ -437,7 +493,8 @@ __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __rest
         if (AN && kind != RTW_SHAPE_MESH) {
             if (inbox) any = analytic_test(sh, ray, seg, pos, cur, slot);
         } else if (sh.n_nodes > 0) {
-            any = lane_mesh_walk<STATS>(sh, cand, ray, q, inbox, prune, cur, pos, slot, ct);
+            if (ALLDS && s == staged_shape) any = lane_mesh_walk<STATS, NT, CAP, true>(sh, cand, lnodes, ltop, ray, q, inbox, prune, cur, pos, slot, ct, dbg_walk, dbg_tri, dbg_flush);
+            else any = lane_mesh_walk<STATS, NT, CAP, false>(sh, cand, lnodes, s == staged_shape ? ltop : 0, ray, q, inbox, prune, cur, pos, slot, ct, dbg_walk, dbg_tri, dbg_flush);
         }
         if (any) {
             seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos;
@@ -447,16 +504,37 @@ __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __rest
     }
 }
 
-template <bool STATS, bool AN>
-__global__ __launch_bounds__(256) void gtrace_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
+// NT threads per block.  STAGE: the block first copies the upper levels of shape `staged_shape`'s tree (RtwShapeDev::tnodes_top records)
+// into LDS -- for the config meshes' 2 399 / 1 935 nodes that is the whole tree -- and its waves walk them there: a step of the walk is
+// one dependent node fetch, ~100 ns from LDS against ~600 ns through L2.
+// STAGE 0: nothing staged; 1: the upper levels (the walk goes on in global memory below them); 2: the whole tree fits (ALLDS)
+template <bool STATS, bool AN, int NT, int CAP, int STAGE>
+__global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int staged_shape)
 {
-    __shared__ uint32_t cand[RTW_GT_CAP * 256];
+    extern __shared__ uint32_t gt_dyn[];                 // [CAP * NT candidate words | staged records]
+    uint32_t* cand = gt_dyn;
     const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
+    if ((uint32_t)blockIdx.x * (uint32_t)NT >= n) return;        // (whole block) the grid is sized from the previous group's list length
+    const float4* lnodes = nullptr; int ltop = 0;
+    if (STAGE) {
+        const RtwShapeDev& s0 = sc->shapes[staged_shape];
+        ltop = s0.tnodes_top;
+        float4* dst = reinterpret_cast<float4*>(gt_dyn + CAP * NT);
+        const float4* src4 = reinterpret_cast<const float4*>(s0.tnodes);
+        for (int i = (int)threadIdx.x; i < ltop * 2; i += NT) dst[i] = gld4(src4, (size_t)i);
+        lnodes = dst;
+        __syncthreads();
+    }
     const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
-    const uint32_t nthreads = gridDim.x * 256u;
+    const uint32_t nthreads = gridDim.x * (uint32_t)NT;
     const uint32_t lane = (uint32_t)lane_id();
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    for (uint32_t base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < n; base += nthreads) {     // wave-uniform
+    int dbg_walk = 0, dbg_tri = 0, dbg_flush = 0;
+#ifdef RTW_TIMING
+    const unsigned long long rtw_t0 = wall_clock64();
+    unsigned long long rtw_t1 = rtw_t0;
+#endif
+    for (uint32_t base = blockIdx.x * (uint32_t)NT + (threadIdx.x & ~63u); base < n; base += nthreads) {     // wave-uniform
         const uint32_t k = base + lane;
         const bool have = k < n;
         const uint32_t slot = have ? src[k] : 0u;
@@ -466,11 +544,255 @@ __global__ __launch_bounds__(256) void gtrace_kernel(const RtwSceneDev* __restri
             ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         }
         int hs = -1, hslot = -1, cs = -1, cslot = -1; f3 pos = mk(0, 0, 0), cpos = mk(0, 0, 0); float seg = ray.dist, cdist = 0.0f;
-        lane_find_intersection<STATS, AN>(sc, cand, ray, have, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct);
+#ifdef RTW_TIMING
+        rtw_t1 = wall_clock64();
+#endif
+        lane_find_intersection<STATS, AN, NT, CAP, (STAGE == 2)>(sc, cand, lnodes, ltop, STAGE ? staged_shape : -1, ray, have, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct,
+                                                                 dbg_walk, dbg_tri, dbg_flush);
         if (have) {
             gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(cs), __int_as_float(cslot));
             if (AN && gb.carry_on) gb.carry[slot] = make_float4(cpos.x, cpos.y, cpos.z, cdist);
+        }
+    }
+#ifdef RTW_TIMING
+    {
+        const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63u) == 0 && w < 16384 && round == 0) {
+            g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = (unsigned long long)dbg_walk;
+            g_rtw_timing[6 * w + 3] = (unsigned long long)dbg_tri; g_rtw_timing[6 * w + 4] = (unsigned long long)dbg_flush; g_rtw_timing[6 * w + 5] = rtw_t1;
+        }
+    }
+#endif
+    if (STATS) flush_counters(sc, ct);
+}
+
+// ---- the same round for a scene that is ONE mesh: persistent waves that refill their lanes ------------------------------------
+// In the kernel above a wave walks 64 rays in lock step until the slowest is done (the mean lane is busy ~40 % of that time) and a
+// block keeps its CU until its slowest wave is done.  Here the grid holds one block per CU and every wave owns an equal contiguous
+// share of the list: whenever RTW_GT_REFILL lanes have finished their walk (or some lane's candidate list is full) the wave runs the
+// noted leaves' triangle tests for all its lanes, writes the finished lanes' hit records and hands those lanes new rays -- out of the
+// 64 it fetched ahead into registers while it walked (one atomic cursor for all waves was measured: 60 k same-address atomics per
+// launch serialise, 14 us per refill).  A lane's sequence of box tests and triangle tests is untouched by what its neighbours do.
+#define RTW_GT_REFILL 16
+template <bool STATS, int NT, int CAP, int STAGE>
+__global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
+{
+    extern __shared__ uint32_t gt_dyn[];                 // [CAP * NT candidate words | staged records]
+    uint32_t* cand = gt_dyn;
+    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
+    const RtwShapeDev& sh = sc->shapes[0];
+    const float4* lnodes = nullptr; int ltop = 0;
+    if (STAGE) {
+        ltop = sh.tnodes_top;
+        float4* dst = reinterpret_cast<float4*>(gt_dyn + CAP * NT);
+        const float4* src4 = reinterpret_cast<const float4*>(sh.tnodes);
+        for (int k = (int)threadIdx.x; k < ltop * 2; k += NT) dst[k] = gld4(src4, (size_t)k);
+        lnodes = dst;
+        __syncthreads();
+    }
+    constexpr bool ALLDS = STAGE == 2;
+    const float4* nd4 = reinterpret_cast<const float4*>(sh.tnodes);
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    const int n_nodes = sh.n_nodes;
+    const bool prune = sc->prune != 0;
+    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
+    const int tid = (int)threadIdx.x;
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    // the lane's ray and the state of its walk
+    bool have = false, tame = true, skx = false, sky = false, skz = false;
+    uint32_t slot = 0u;
+    Ray r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.dist = 0.0f;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, eps_t = 0.0f, cur = 0.0f;
+    f3 pos = mk(0, 0, 0);
+    int i = n_nodes, leaf_out = -1, ncand = 0;
+    // the wave's share of the list: every nw-th batch of 64 entries (neighbouring entries come from neighbouring pixels and cost alike:
+    // contiguous shares were measured 2 x out of balance), fetched one batch ahead into staging registers
+    uint32_t rnext, st_count, st_used = 0u, st_slot = 0u;
+    float4 st_s0 = make_float4(0.f, 0.f, 0.f, 0.f), st_s1 = st_s0;
+    const uint32_t rstride = gridDim.x * (uint32_t)(NT / 64) * 64u;
+    {
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)(NT / 64) + (threadIdx.x >> 6)));
+        rnext = wv * 64u;
+        st_count = rnext < n ? (n - rnext < 64u ? n - rnext : 64u) : 0u;
+        const uint32_t k = rnext + (uint32_t)lane_id();
+        if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
+        rnext += rstride;
+    }
+#ifdef RTW_TIMING
+    int dbg_walk = 0, dbg_tri = 0, dbg_ev = 0; unsigned long long dbg_refill = 0ull;
+    const unsigned long long rtw_t0 = wall_clock64();
+#endif
+    for (;;) {
+#ifdef RTW_TIMING
+        const unsigned long long rtw_e0 = wall_clock64(); dbg_ev++;
+#endif
+        // ---- hand the idle lanes new rays, out of the 64 the wave fetched ahead (lane e of the staging registers holds entry e) ----
+        if (st_used < st_count) {
+            const unsigned long long idle = __ballot(!have);
+            const uint32_t c = (uint32_t)__popcll(idle);
+            if (c != 0u) {
+                const uint32_t avail = st_count - st_used, take = c < avail ? c : avail;
+                const uint32_t rank = (uint32_t)mbcnt(idle);
+                const int from = (int)((st_used + rank) & 63u) * 4;
+                const uint32_t g_slot = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)st_slot);
+                const float g0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s0.x))), g1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s0.y)));
+                const float g2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s0.z))), g3 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s0.w)));
+                const float g4 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s1.x))), g5 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s1.y)));
+                const float g6 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(st_s1.z)));
+                if (!have && rank < take) {
+                    slot = g_slot;
+                    r.o = mk(g0, g1, g2); r.dist = g3; r.d = mk(g4, g5, g6);
+                    have = true;
+                    if (STATS) { ct.rays++; ct.boxes++; }
+                    tame = ray_is_tame(r);
+                    skx = near_zero(r.d.x); sky = near_zero(r.d.y); skz = near_zero(r.d.z);
+                    ix = (!tame && skx) ? 0.0f : 1.0f / r.d.x; iy = (!tame && sky) ? 0.0f : 1.0f / r.d.y; iz = (!tame && skz) ? 0.0f : 1.0f / r.d.z;
+                    eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
+                    cur = r.dist; pos = mk(0, 0, 0); leaf_out = -1; ncand = 0;
+                    float t0, t1;       // the shape's culling box (Src/RayTracerScene.cpp:109)
+                    i = slab_exact(r, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1) ? 0 : n_nodes;
+                }
+                st_used += take;
+                if (st_used == st_count) {          // fetch the next 64 now: they arrive while the wave walks
+                    st_count = rnext < n ? (n - rnext < 64u ? n - rnext : 64u) : 0u; st_used = 0u;
+                    const uint32_t k = rnext + (uint32_t)lane_id();
+                    if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
+                    rnext += rstride;
+                }
+            }
+        }
+        const bool exhausted = st_used >= st_count;
+#ifdef RTW_TIMING
+        dbg_refill += wall_clock64() - rtw_e0;
+#endif
+        if (__ballot(have) == 0ull) break;
+        const bool any_untame = __ballot(have && !tame) != 0ull;
+        const float far_t = prune ? cur + (eps_t + 1.0e-4f * cur) : INFINITY;
+        const float neg_eps = prune ? -eps_t : -INFINITY;
+        // ---- walk ----
+        if (!any_untame) {
+            const rtw_v2f ox = { r.o.x, r.o.x }, oy = { r.o.y, r.o.y }, oz = { r.o.z, r.o.z };
+            const rtw_v2f vx = { ix, ix }, vy = { iy, iy }, vz = { iz, iz };
+            for (;;) {
+                const bool walking = have & (i < n_nodes);
+                if (__ballot(walking) == 0ull) break;
+                RTW_GT_COUNT(dbg_walk);
+                if (walking) {
+                    float4 a, b;
+                    if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
+                    else { a = gld4(nd4, 2 * (size_t)i); b = gld4(nd4, 2 * (size_t)i + 1); }
+                    const int skip = __float_as_int(b.z), link = __float_as_int(b.w);
+                    const rtw_v2f bx = { a.x, a.y }, by = { a.z, a.w }, bz = { b.x, b.y };
+                    const rtw_v2f tx = (bx - ox) * vx, ty = (by - oy) * vy, tz = (bz - oz) * vz;
+                    const float tmin = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+                    const float tmax = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+                    const bool hit = (tmax > tmin) & !(tmin > far_t) & !(tmax < neg_eps);
+                    const bool leaf = link >= 0;
+                    if (STATS) ct.boxes++;
+                    if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
+                    i = (hit & !leaf) ? ~link : skip;
+                }
+                if (__ballot(ncand == CAP) != 0ull) break;
+                if (!exhausted && __popcll(__ballot(have & (i >= n_nodes))) >= RTW_GT_REFILL) break;
+            }
+        } else {
+            for (;;) {
+                const bool walking = have & (i < n_nodes);
+                if (__ballot(walking) == 0ull) break;
+                RTW_GT_COUNT(dbg_walk);
+                if (walking) {
+                    float4 a, b;
+                    if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
+                    else { a = gld4(nd4, 2 * (size_t)i); b = gld4(nd4, 2 * (size_t)i + 1); }
+                    const int skip = __float_as_int(b.z), link = __float_as_int(b.w);
+                    const float x1 = (a.x - r.o.x) * ix, x2 = (a.y - r.o.x) * ix;
+                    const float y1 = (a.z - r.o.y) * iy, y2 = (a.w - r.o.y) * iy;
+                    const float z1 = (b.x - r.o.z) * iz, z2 = (b.y - r.o.z) * iz;
+                    const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                    const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                    bool hit = (tmax > tmin) & !(tmin > far_t) & !(tmax < neg_eps);
+                    float emin = -FLT_MAX, emax = FLT_MAX;      // RRay::TestIntersectionWithAabb as written, for the lanes that need it
+                    if (!skx) { emin = ref_max(emin, ref_min(x1, x2)); emax = ref_min(emax, ref_max(x1, x2)); }
+                    if (!sky) { emin = ref_max(emin, ref_min(y1, y2)); emax = ref_min(emax, ref_max(y1, y2)); }
+                    if (!skz) { emin = ref_max(emin, ref_min(z1, z2)); emax = ref_min(emax, ref_max(z1, z2)); }
+                    if (!tame) hit = emax > emin;
+                    const bool leaf = link >= 0;
+                    if (STATS) ct.boxes++;
+                    if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
+                    i = (hit & !leaf) ? ~link : skip;
+                }
+                if (__ballot(ncand == CAP) != 0ull) break;
+                if (!exhausted && __popcll(__ballot(have & (i >= n_nodes))) >= RTW_GT_REFILL) break;
+            }
+        }
+        // ---- the noted leaves' triangle tests: every lane through its own list in order, the next record fetched ahead ----
+        {
+            bool mine = 0 < ncand;
+            int leaf = mine ? (int)lldu(cand, tid) : 0;
+            float4 ta = gld4(tr4, 4 * (size_t)leaf), tb = gld4(tr4, 4 * (size_t)leaf + 1), tc = gld4(tr4, 4 * (size_t)leaf + 2);
+            float td = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)leaf + 12);
+            for (int j = 0; __ballot(mine) != 0ull; j++) {
+                RTW_GT_COUNT(dbg_tri);
+                const bool nmine = j + 1 < ncand;
+                const int nleaf = nmine ? (int)lldu(cand, (j + 1) * NT + tid) : 0;
+                const float4 na = gld4(tr4, 4 * (size_t)nleaf), nb = gld4(tr4, 4 * (size_t)nleaf + 1), nc = gld4(tr4, 4 * (size_t)nleaf + 2);
+                const float nd = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)nleaf + 12);
+                if (mine) {
+                    if (STATS) ct.tris++;
+                    f3 cp; float dist;
+                    if (triangle_test(r, cur, ta, tb, tc, td, cp, dist)) { cur = dist; pos = cp; leaf_out = leaf; }
+                }
+                mine = nmine; leaf = nleaf; ta = na; tb = nb; tc = nc; td = nd;
+            }
+            ncand = 0;
+        }
+        // ---- lanes whose walk is complete: FindIntersectionWithScene's result for the one shape ----
+        if (have & (i >= n_nodes)) {
+            const int hs = leaf_out >= 0 ? 0 : -1;
+            gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, cur);
+            gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(leaf_out), __int_as_float(-1), __int_as_float(-1));
+            have = false;
+        }
+    }
+#ifdef RTW_TIMING
+    {
+        const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63u) == 0 && w < 16384 && round == 0) {
+            g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = (unsigned long long)dbg_walk;
+            g_rtw_timing[6 * w + 3] = (unsigned long long)dbg_tri; g_rtw_timing[6 * w + 4] = (unsigned long long)dbg_ev; g_rtw_timing[6 * w + 5] = rtw_t0 + dbg_refill;
+        }
+    }
+#endif
+    if (STATS) flush_counters(sc, ct);
+}
+
+// The same round for a SHORT list: a whole wave per ray over the flat hierarchy (wave_find_intersection, rtw_wave_kernels.h).  A ray
+// per lane needs hundreds of thousands of rays to fill the chip and ~100 dependent steps per ray; below that the wave-per-ray walk's
+// handful of dependent steps wins (the host picks by the previous group's list length).  Not for texel-inheritance scenes.
+template <bool STATS, bool AN, int NT>
+__global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
+{
+    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
+    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
+    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;
+    uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
+    const FlatSrc shape0 = flat_src_of(sc->shapes[0]);
+    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
+    const int n_shapes = sc->n_shapes;
+    const bool prune = sc->prune != 0;
+    const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);
+    Counters ct = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t k = wave; k < n; k += nwaves) {
+        const int ku = __builtin_amdgcn_readfirstlane((int)k);
+        const int q = (int)cldu(src, ku);
+        const float4 s0 = cld4(gb.state, q * 3), s1 = cld4(gb.state, q * 3 + 1);
+        Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+        int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
+        wave_find_intersection<STATS, 0, AN>(sc, 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
+        if (lane_id() == 0) {
+            gb.hit[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
+            gb.hit[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), __int_as_float(-1), __int_as_float(-1));
         }
     }
     if (STATS) flush_counters(sc, ct);

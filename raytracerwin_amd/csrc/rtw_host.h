@@ -39,6 +39,8 @@ struct HostMesh {
     std::vector<RtwWide> wides;        // 16-wide collapse, BFS order
     int wide_depth = 0;
     int max_depth = 0;
+    std::vector<RtwPNode> tnodes;      // the tree with explicit links, upper levels first (RtwShapeDev::tnodes)
+    int tnodes_top = 0;
     std::vector<float> flat[3];        // flat hierarchy over the leaves in preorder, see RtwShapeDev::flat
     int flat_n[3] = { 0, 0, 0 }, flat_pad[3] = { 0, 0, 0 };
     int n_tris() const { return (int)(point_idx.size() / 3); }
@@ -56,6 +58,8 @@ void triangle_plane(const float p0[3], const float p1[3], const float p2[3], flo
 void build_tree(HostMesh& m);
 // 4-wide collapse of m.nodes (slot order = preorder), numbered breadth-first.
 void build_quads(HostMesh& m);
+// The tree with explicit links, the at most `top_budget` records of its upper levels first (needs build_tree()).
+void build_tnodes(HostMesh& m, int top_budget);
 // Flat hierarchy: leaf boxes in preorder and the unions of every 16 / 256 consecutive leaves (needs build_tree()).
 void build_flat(HostMesh& m);
 // Screen-space bins of the reference camera (Src/RayTracerProgram.cpp:133-165: origin (0,0,7), image plane z = -0.5)

@@ -15,6 +15,12 @@ struct RtwNode {            // 2 x 16 B
 };
 static_assert(sizeof(RtwNode) == 32, "RtwNode");
 
+struct RtwPNode {           // 2 x 16 B
+    float min_x, max_x, min_y, max_y;
+    float min_z, max_z; int32_t skip; int32_t link;   // link >= 0: a leaf's slot; < 0: internal, left child = record -1 - link
+};
+static_assert(sizeof(RtwPNode) == 32, "RtwPNode");
+
 struct RtwTri {             // 4 x 16 B
     float p0x, p0y, p0z, nx;
     float p1x, p1y, p1z, ny;
@@ -88,7 +94,13 @@ struct RtwShapeDev {
     // is one packed subtract and one packed multiply; flat_pad[l] entries are allocated (whole waves may read past flat_n[l]).
     const float* flat[3];
     int32_t flat_n[3], flat_pad[3];
-    int32_t pad_flat0, pad_flat1;
+    // the same binary tree once more for the ray-per-lane walk (gtrace_kernel): RtwNode records with EXPLICIT links -- `skip` as in
+    // `nodes`, `tri` >= 0 a leaf's slot, < 0 an internal node whose left child is record -1 - tri -- stored so that the tnodes_top
+    // records of the tree's upper levels come first, in preorder (a block stages them in LDS), followed by the subtrees below them,
+    // each contiguous in preorder.  The walk visits the records in the reference's order whatever their place in memory.
+    // A record is RtwPNode: the box as (min, max) PAIRS per axis, so that (pair - origin) * reciprocal is one packed subtract and one
+    // packed multiply per axis (v_pk_add_f32 / v_pk_mul_f32: component-wise the reference's float operations).
+    const struct RtwPNode* tnodes;
     float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
     int32_t n_quads, quad_depth;
     int32_t n_nodes, n_tris;
@@ -101,7 +113,7 @@ struct RtwShapeDev {
     float pa[3], pb[3], radius;
     float pc[3], pn[3], pd1;        // triangle (RTriangle, Src/Shapes.h:106-130): pa, pb, pc = Points[0..2]; pn = its face normal and pd1 = dot(pn, pa) as
                                     // RRay::TestIntersectionWithTriangle computes them at every test (Src/RRay.cpp:138-145), here once on the host
-    int32_t pad_kind;
+    int32_t tnodes_top;
     RtwTexture textures[RTW_DEV_MAX_TEXTURES];
     RtwMaterialNode material[RTW_DEV_MAX_MATERIAL_NODES];
 };

@@ -135,6 +135,9 @@ struct rtw_context {
     int known_ground[32];
     int group_paths = 2 << 20;          // passes are grouped until a launch holds about this many paths ...
     int group_max = 16;                 // ... and at most this many passes (a power of two)
+    int wave_below = 100000;            // trace rounds with fewer rays than this (previous group's count) run a wave per ray instead of a ray per lane
+    int trace_persist = 1;              // one-mesh scenes: persistent trace waves that refill their lanes
+    int trace_stage = 1;                // the ray-per-lane trace kernel stages the first mesh's upper tree levels in LDS (1024-thread blocks)
     int last_pipeline = -1;             // the pipeline the latest render call actually ran (rtw_last_pass_pipeline)
 };
 
@@ -286,6 +289,9 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         ctx->pipeline = value;
         return RTW_OK;
     }
+    if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "trace_persist") == 0) { ctx->trace_persist = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "trace_stage") == 0) { ctx->trace_stage = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "group_max") == 0) {
         if (value < 1 || value > 64 || (value & (value - 1)) != 0) return fail(RTW_ERR_INVALID, "group_max must be a power of two in 1..64");
@@ -572,7 +578,7 @@ int rtw_scene_commit(rtw_scene* scene)
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
     if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
     if (!scene->ctx) {      // host-only scene: build the flattened trees for inspection, nothing to upload
-        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_quads(*m); rtw::build_flat(*m); }
+        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_quads(*m); rtw::build_tnodes(*m, RTW_TNODES_TOP_BUDGET); rtw::build_flat(*m); }
         scene->committed = true;
         return RTW_OK;
     }
@@ -603,6 +609,9 @@ int rtw_scene_commit(rtw_scene* scene)
             if ((rc = upload(scene, m.wides, &d.wides)) != RTW_OK) return rc;
             d.n_wides = (int)m.wides.size(); d.wide_depth = m.wide_depth;
         }
+        rtw::build_tnodes(m, RTW_TNODES_TOP_BUDGET);
+        if ((rc = upload(scene, m.tnodes, &d.tnodes)) != RTW_OK) return rc;
+        d.tnodes_top = m.tnodes_top;
         rtw::build_flat(m);
         for (int l = 0; l < 3; l++) {
             if ((rc = upload(scene, m.flat[l], &d.flat[l])) != RTW_OK) return rc;
@@ -1142,6 +1151,13 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.has_analytic = scene->has_analytic; tune.carry = carry;
     tune.counters_clean = cx->group_clean;
     tune.cu_count = cx->cu_count;
+    if (cx->trace_stage) {      // the first mesh's upper tree levels live in the trace blocks' LDS
+        for (size_t k = 0; k < scene->meshes.size(); k++)
+            if (scene->meshes[k]->kind == RTW_SHAPE_MESH && scene->meshes[k]->tnodes_top > 0) { tune.staged_shape = (int)k; tune.staged_top = scene->meshes[k]->tnodes_top; tune.staged_all = tune.staged_top == (int)scene->meshes[k]->tnodes.size(); break; }
+    }
+    tune.single_mesh = scene->meshes.size() == 1 && scene->meshes[0]->kind == RTW_SHAPE_MESH && !scene->meshes[0]->nodes.empty();
+    tune.persist = cx->trace_persist != 0;
+    tune.wave_below = cx->wave_below;
     tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
     rtw_context::GroupKey key; key.scene = scene; key.capacity = (long long)capacity; key.max_bounce = max_bounce; key.preview = p.preview; key.n_passes = n_passes;

@@ -419,6 +419,56 @@ void build_quads(HostMesh& m)
 }
 
 // ---------------------------------------------------------------------------------------
+// The tree with explicit links for the ray-per-lane walk.  Depth limit D = the deepest level such that the nodes of depth <= D
+// number at most top_budget; those come first (preorder), then, for every internal node of depth D in preorder, the nodes below it
+// (preorder).  A record's links name records of this array; following them visits the nodes in the order KdNode::TestRayIntersection
+// does (Src/KdTree.cpp:128-195), exactly like `nodes` with left = i + 1.
+// ---------------------------------------------------------------------------------------
+void build_tnodes(HostMesh& m, int top_budget)
+{
+    m.tnodes.clear(); m.tnodes_top = 0;
+    const int n = (int)m.nodes.size();
+    if (n == 0) return;
+    std::vector<int> depth((size_t)n, 0);
+    std::vector<int> per_level;
+    {   // preorder: the left child of i is i + 1, the right child is the left child's skip target
+        depth[0] = 0;
+        for (int i = 0; i < n; i++) {
+            if ((int)per_level.size() <= depth[(size_t)i]) per_level.resize((size_t)depth[(size_t)i] + 1, 0);
+            per_level[(size_t)depth[(size_t)i]]++;
+            if (m.nodes[(size_t)i].tri < 0) {
+                const int l = i + 1, r = m.nodes[(size_t)l].skip;
+                depth[(size_t)l] = depth[(size_t)i] + 1;
+                if (r < n) depth[(size_t)r] = depth[(size_t)i] + 1;
+            }
+        }
+    }
+    int D = -1, count = 0;
+    for (size_t d = 0; d < per_level.size(); d++) { if (count + per_level[d] > top_budget) break; count += per_level[d]; D = (int)d; }
+    std::vector<int> order; order.reserve((size_t)n);
+    for (int i = 0; i < n; i++) if (depth[(size_t)i] <= D) order.push_back(i);
+    m.tnodes_top = (int)order.size();
+    if (D < 0) { for (int i = 0; i < n; i++) order.push_back(i); }      // nothing fits: plain preorder
+    else {
+        for (int i = 0; i < n; i++) {
+            if (depth[(size_t)i] != D || m.nodes[(size_t)i].tri >= 0) continue;
+            for (int j = i + 1; j < m.nodes[(size_t)i].skip; j++) order.push_back(j);      // the subtree below i, preorder
+        }
+    }
+    std::vector<int> place((size_t)n + 1, n);
+    for (int k = 0; k < n; k++) place[(size_t)order[(size_t)k]] = k;
+    m.tnodes.resize((size_t)n);
+    for (int k = 0; k < n; k++) {
+        const RtwNode& src = m.nodes[(size_t)order[(size_t)k]];
+        RtwPNode t;
+        t.min_x = src.min_x; t.max_x = src.max_x; t.min_y = src.min_y; t.max_y = src.max_y; t.min_z = src.min_z; t.max_z = src.max_z;
+        t.skip = place[(size_t)src.skip];
+        t.link = src.tri >= 0 ? src.tri : -1 - place[(size_t)order[(size_t)k] + 1];
+        m.tnodes[(size_t)k] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Flat hierarchy.  Leaves in preorder; level l + 1 entry k = union of level l entries [16k, 16k + 16).
 // A ray whose line meets a leaf's own box meets every union that contains it (the slab test is monotone
 // in the bounds), so testing unions first only culls; the leaf's own box then gets the reference's test.
