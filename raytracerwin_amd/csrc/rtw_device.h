@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <climits>
 
 #include "rtw_types.h"
 
@@ -56,7 +57,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
 // device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)
 size_t pipeline_counters_offset(long long work_items, int max_bounce);
 // ---- pass-batched pipeline (pipeline 4, rtw_group_kernels.h) ----
-struct GroupLayout { size_t counters_off, rad_off, state_off, hit_off, carry_off, levels_off, list0_off, list1_off, total; };
+struct GroupLayout { size_t counters_off, rad_off, state_off, hit_off, carry_off, levels_off, list0_off, list1_off, overflow_off, total; };
 // device bytes of a group's workspace: `capacity` path slots (busy tiles x 64 x sub-samples x passes of the group, rounded up to a power of two of passes)
 size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupLayout* out);
 struct GroupTuning {
@@ -70,6 +71,8 @@ struct GroupTuning {
     int round_hint[32];            // list lengths of the previous group per round (-1 = unknown): they size the launches
     int cu_count = 256;
     bool single_mesh = false, persist = true; // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
+    int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
+    int overflow_hint[32];                   // how many rays that were in the previous group, per round (-1 = unknown)
     int wave_below = 0;                      // a trace round whose list (previous group's length) is shorter than this runs a wave per ray
     bool staged_all = false;                 // ... and that is the shape's whole tree
     int staged_shape = -1, staged_top = 0;   // the trace blocks stage the first staged_top tnodes records of this shape in LDS (-1: nothing staged)

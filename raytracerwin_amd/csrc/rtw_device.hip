@@ -2245,7 +2245,8 @@ size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupL
     l.levels_off = l.carry_off + (carry ? up(cap * 16) : 0);
     l.list0_off = l.levels_off + up(cap * (size_t)(max_bounce > 0 ? max_bounce : 1) * 48);
     l.list1_off = l.list0_off + up(cap * 4);
-    l.total = l.list1_off + up(cap * 4);
+    l.overflow_off = l.list1_off + up(cap * 4);
+    l.total = l.overflow_off + up(cap * 4);
     if (out) *out = l;
     return l.total;
 }
@@ -2260,7 +2261,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     GroupBufs gb;
     gb.rad = (float4*)(w + l.rad_off); gb.state = (float4*)(w + l.state_off); gb.hit = (float4*)(w + l.hit_off);
     gb.carry = tune.carry ? (float4*)(w + l.carry_off) : nullptr; gb.levels = (float4*)(w + l.levels_off);
-    gb.list0 = (uint32_t*)(w + l.list0_off); gb.list1 = (uint32_t*)(w + l.list1_off); gb.counters = (uint32_t*)(w + l.counters_off);
+    gb.list0 = (uint32_t*)(w + l.list0_off); gb.list1 = (uint32_t*)(w + l.list1_off); gb.overflow = (uint32_t*)(w + l.overflow_off); gb.counters = (uint32_t*)(w + l.counters_off);
     gb.capacity = (uint32_t)tune.capacity; gb.carry_on = tune.carry ? 1 : 0;
     if (!tune.counters_clean) { hipError_t e = hipMemsetAsync(gb.counters, 0, 256, stream); if (e != hipSuccess) return (int)e; }
     bool forked = false;
@@ -2326,20 +2327,20 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                     if (blocks > cap) blocks = cap;
                     const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
                     if (tune.has_analytic) {
-                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
-                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
                     } else {
-                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
-                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1);
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
                     }
                 } else if (tune.single_mesh && tune.persist) {
                     // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
 #define RTW_LAUNCH_GP(NT_, CAP_, STG, BLOCKS, DYN)                                                                                               \
                     do {                                                                                                                        \
                         if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1); } \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget); } \
                         else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1); } \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget); } \
                     } while (0)
                     if (tune.staged_shape == 0 && tune.staged_top > 0) {
                         unsigned sbl = (tb + 3) / 4;
@@ -2354,6 +2355,16 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         RTW_LAUNCH_GP(256, RTW_GT_CAP, 0, bl, dyn);
                     }
 #undef RTW_LAUNCH_GP
+                    if (tune.visit_budget < INT32_MAX) {        // the rays that ran out of budget: a wave each
+                        constexpr int NTV = 128;
+                        long long want = tune.overflow_hint[r - 1] >= 0 ? (long long)tune.overflow_hint[r - 1] * 2 + 256 : 16384;
+                        long long blocks = (want + NTV / 64 - 1) / (NTV / 64);
+                        const long long cap = (long long)tune.cu_count * 64;
+                        if (blocks > cap) blocks = cap;
+                        const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1);
+                    }
                 } else if (tune.staged_shape >= 0 && tune.staged_top > 0) {
                     const unsigned sbl = (tb + 3) / 4;          // 1024-thread blocks
                     const size_t dyn = (size_t)RTW_GT_CAP_STAGED * 1024 * 4 + (size_t)tune.staged_top * 32;

@@ -38,6 +38,7 @@ struct GroupBufs {
     float4* __restrict__ levels;    // [capacity * max_bounce * 3]
     uint32_t* __restrict__ list0;   // ray lists (slots), ping-pong
     uint32_t* __restrict__ list1;
+    uint32_t* __restrict__ overflow;// rays the budgeted ray-per-lane walk handed over to the wave-per-ray kernel; its length: counters[40 + round]
     uint32_t* __restrict__ counters;// [r] = length of round r's list; [64 + r] = the same at the end of the previous group (for the host)
     uint32_t capacity;
     int32_t carry_on;               // the scene has an analytic shape after a textured mesh (Src/RRay.cpp:53-58,75-80: its hits keep the texel)
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
 // launch serialise, 14 us per refill).  A lane's sequence of box tests and triangle tests is untouched by what its neighbours do.
 #define RTW_GT_REFILL 16
 template <bool STATS, int NT, int CAP, int STAGE>
-__global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
+__global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
 {
     extern __shared__ uint32_t gt_dyn[];                 // [CAP * NT candidate words | staged records]
     uint32_t* cand = gt_dyn;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     Ray r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.dist = 0.0f;
     float ix = 0.0f, iy = 0.0f, iz = 0.0f, eps_t = 0.0f, cur = 0.0f;
     f3 pos = mk(0, 0, 0);
-    int i = n_nodes, leaf_out = -1, ncand = 0;
+    int i = n_nodes, leaf_out = -1, ncand = 0, visits = 0;
     // the wave's share of the list: every nw-th batch of 64 entries (neighbouring entries come from neighbouring pixels and cost alike:
     // contiguous shares were measured 2 x out of balance), fetched one batch ahead into staging registers
     uint32_t rnext, st_count, st_used = 0u, st_slot = 0u;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     skx = near_zero(r.d.x); sky = near_zero(r.d.y); skz = near_zero(r.d.z);
                     ix = (!tame && skx) ? 0.0f : 1.0f / r.d.x; iy = (!tame && sky) ? 0.0f : 1.0f / r.d.y; iz = (!tame && skz) ? 0.0f : 1.0f / r.d.z;
                     eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
-                    cur = r.dist; pos = mk(0, 0, 0); leaf_out = -1; ncand = 0;
+                    cur = r.dist; pos = mk(0, 0, 0); leaf_out = -1; ncand = 0; visits = 0;
                     float t0, t1;       // the shape's culling box (Src/RayTracerScene.cpp:109)
                     i = slab_exact(r, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1) ? 0 : n_nodes;
                 }
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     if (STATS) ct.boxes++;
                     if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
                     i = (hit & !leaf) ? ~link : skip;
+                    visits++;
                 }
                 if (__ballot(ncand == CAP) != 0ull) break;
                 if (!exhausted && __popcll(__ballot(have & (i >= n_nodes))) >= RTW_GT_REFILL) break;
@@ -721,9 +723,26 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     if (STATS) ct.boxes++;
                     if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
                     i = (hit & !leaf) ? ~link : skip;
+                    visits++;
                 }
                 if (__ballot(ncand == CAP) != 0ull) break;
                 if (!exhausted && __popcll(__ballot(have & (i >= n_nodes))) >= RTW_GT_REFILL) break;
+            }
+        }
+        // ---- a ray that has used up its budget of node visits leaves for the wave-per-ray kernel that follows (it starts over there:
+        // a whole wave on one ray shortens the chain of dependent steps that would otherwise keep this launch waiting) ----
+        {
+            const bool over = have & (i < n_nodes) & (visits > budget);
+            const unsigned long long om = __ballot(over);
+            if (om != 0ull) {
+                uint32_t base = 0u;
+                if (lane_id() == 0) base = atomicAdd(&gb.counters[40 + round], (uint32_t)__popcll(om));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (over) {
+                    gb.overflow[base + (uint32_t)mbcnt(om)] = slot;
+                    if (STATS) ct.rays--;        // the query is counted by the kernel that takes it over (the box / triangle tests run so far were run)
+                    have = false; ncand = 0; i = n_nodes;
+                }
             }
         }
         // ---- the noted leaves' triangle tests: every lane through its own list in order, the next record fetched ahead ----
@@ -770,15 +789,17 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
 // The same round for a SHORT list: a whole wave per ray over the flat hierarchy (wave_find_intersection, rtw_wave_kernels.h).  A ray
 // per lane needs hundreds of thousands of rays to fill the chip and ~100 dependent steps per ray; below that the wave-per-ray walk's
 // handful of dependent steps wins (the host picks by the previous group's list length).  Not for texel-inheritance scenes.
+// from_overflow: the list is the one the budgeted ray-per-lane kernel of this round filled.
 template <bool STATS, bool AN, int NT>
-__global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
+__global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int from_overflow)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
-    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
+    const uint32_t nl = from_overflow ? gb.counters[40 + round] : gb.counters[round];
+    const uint32_t n = nl < gb.capacity ? nl : gb.capacity;
     if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;
     uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
     const FlatSrc shape0 = flat_src_of(sc->shapes[0]);
-    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
+    const uint32_t* __restrict__ src = from_overflow ? gb.overflow : (round & 1 ? gb.list1 : gb.list0);
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
     const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);

@@ -133,8 +133,10 @@ struct rtw_context {
                       bool operator==(const GroupKey& o) const { return scene == o.scene && capacity == o.capacity && max_bounce == o.max_bounce && preview == o.preview && n_passes == o.n_passes; } };
     GroupKey gcounters_key, known_gkey;
     int known_ground[32];
-    int group_paths = 2 << 20;          // passes are grouped until a launch holds about this many paths ...
-    int group_max = 16;                 // ... and at most this many passes (a power of two)
+    int known_goverflow[24];
+    int visit_budget = 256;             // one-mesh scenes with a big tree: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
+    int group_paths = 4 << 20;          // passes are grouped until a launch holds about this many paths ...
+    int group_max = 64;                 // ... and at most this many passes (a power of two)
     int wave_below = 100000;            // trace rounds with fewer rays than this (previous group's count) run a wave per ray instead of a ray per lane
     int trace_persist = 1;              // one-mesh scenes: persistent trace waves that refill their lanes
     int trace_stage = 1;                // the ray-per-lane trace kernel stages the first mesh's upper tree levels in LDS (1024-thread blocks)
@@ -240,6 +242,7 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipEventCreateWithFlags(&c->gcounters_event, hipEventDisableTiming));
     for (int i = 0; i < 64; i++) c->h_gcounters[i] = 0;
     for (int r = 0; r < 32; r++) c->known_ground[r] = -1;
+    for (int r = 0; r < 24; r++) c->known_goverflow[r] = -1;
     for (int i = 0; i < 64; i++) c->h_counters[i] = 0;
     for (int r = 0; r < 32; r++) c->known_rounds[r] = -1;
     HIP_TRY(hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)));
@@ -289,6 +292,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         ctx->pipeline = value;
         return RTW_OK;
     }
+    if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "trace_persist") == 0) { ctx->trace_persist = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "trace_stage") == 0) { ctx->trace_stage = value ? 1 : 0; return RTW_OK; }
@@ -1157,15 +1161,20 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     }
     tune.single_mesh = scene->meshes.size() == 1 && scene->meshes[0]->kind == RTW_SHAPE_MESH && !scene->meshes[0]->nodes.empty();
     tune.persist = cx->trace_persist != 0;
-    tune.wave_below = cx->wave_below;
+    // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
+    tune.visit_budget = (cx->visit_budget > 0 && tune.single_mesh && scene->meshes[0]->nodes.size() > 4096) ? cx->visit_budget : INT32_MAX;
+    tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 3 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
     tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
     rtw_context::GroupKey key; key.scene = scene; key.capacity = (long long)capacity; key.max_bounce = max_bounce; key.preview = p.preview; key.n_passes = n_passes;
     if (cx->gcounters_pending && hipEventQuery(cx->gcounters_event) == hipSuccess) {
         cx->known_gkey = cx->gcounters_key; cx->gcounters_pending = false;
         for (int r = 0; r < 32; r++) cx->known_ground[r] = (int)cx->h_gcounters[r];
+        for (int r = 0; r < 24; r++) cx->known_goverflow[r] = (int)cx->h_gcounters[40 + r];
     }
     for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_gkey == key) ? cx->known_ground[r] : -1;
+    for (int r = 0; r < 24; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? cx->known_goverflow[r] : -1;
+    for (int r = 24; r < 32; r++) tune.overflow_hint[r] = -1;
     cx->group_clean = false;
     const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws, g, tune, cx->stats_enabled, cx->stream);
     if (e != hipSuccess) return hip_fail(e, "group launch");

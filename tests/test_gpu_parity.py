@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 import raytracerwin_amd as R  # noqa: E402
 
+DEFAULT_PIPELINE = 4        # pass-batched: screen bins + a ray per lane, K passes per set of launches
+
 
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
@@ -306,7 +308,7 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
     # (pipeline, packets, path_lanes, wave_fused, wave_stage): 3 = screen bins + a wave per secondary ray
     for mode, packets, lanes, fused, stage in ((0, 0, 4, 0, -1), (1, 0, 4, 0, -1), (1, 0, 1, 0, -1), (1, 1, 4, 0, -1), (1, 1, 1, 0, -1), (1, 0, 16, 0, -1),
                                                (1, 1, 16, 0, -1), (2, 1, 16, 0, -1), (3, 1, 16, 0, -1), (3, 1, 16, 1, -1), (3, 1, 16, 0, 0),
-                                               (3, 1, 16, 0, 1), (3, 1, 16, 1, 2), (3, 1, 16, 2, -1), (3, 1, 16, 2, 2)):
+                                               (3, 1, 16, 0, 1), (3, 1, 16, 1, 2), (3, 1, 16, 2, -1), (3, 1, 16, 2, 2), (4, 1, 16, 0, -1), (4, 1, 16, 0, 0)):
         ctx.set_option("pipeline", mode)
         ctx.set_option("packets", packets)
         ctx.set_option("path_lanes", lanes)
@@ -314,13 +316,16 @@ def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
         ctx.set_option("wave_tail", 1 if fused == 2 else 0)
         ctx.set_option("wave_stage", stage)
         ctx.set_option("direct_slots", 0 if (mode == 3 and stage == 1) else 1)       # the stage-1 run also takes the queue + shade(0) route
-        ctx.set_option("sky_split", 0 if (mode == 3 and stage == 0) else 1)          # the stage-0 run also keeps every tile in one primary kernel
+        ctx.set_option("sky_split", 0 if (mode in (3, 4) and stage == 0) else 1)     # the stage-0 run also keeps every tile in one primary kernel
+        ctx.set_option("trace_persist", 0 if (mode == 4 and stage == 0) else 1)      # ... and, pass-batched, walks without refilling lanes, nothing staged, no wave-per-ray rounds
+        ctx.set_option("trace_stage", 0 if (mode == 4 and stage == 0) else 1)
+        ctx.set_option("wave_below", 0 if (mode == 4 and stage == 0) else 100000)
         ctx.stats_enable(True)
         ctx.stats_reset()
         a, b = render_frame(ctx, s, W, H, ns, depth, preview, 4321, 0, 2)
         out.append((a, b, ctx.stats()))
         ctx.stats_enable(False)
-    ctx.set_option("pipeline", 3)
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
     ctx.set_option("packets", 1)
     ctx.set_option("path_lanes", 16)
     ctx.set_option("wave_fused", 0)
@@ -359,6 +364,7 @@ def test_render_passes_graph_replay_equals_pass_by_pass(ctx, mesh, ns, depth, wo
     device) accumulates exactly what pass-by-pass rtw_render_tasks calls do, from any first pass, with the graph on or off."""
     W, H = 640, 360
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.8, 0.9, 1.0)))
+    ctx.set_option("pipeline", 3)        # (the one-pass-per-set-of-launches pipeline; the pass-batched default has its own test below)
     ref = R.Framebuffer(ctx, W, H)
     for rank in range(world):
         for p in range(3, 3 + 9):
@@ -373,6 +379,7 @@ def test_render_passes_graph_replay_equals_pass_by_pass(ctx, mesh, ns, depth, wo
         a, b = fb.read_float(), fb.resolve_argb()
         assert (bits(a) == bits(ra)).all() and (b == rb).all(), graph
     ctx.set_option("use_graph", 0)
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
 
 
 @pytest.mark.gpu
@@ -387,6 +394,9 @@ def test_config5_shape_4k_depth8_pipelines_agree_and_tasks_compose(ctx):
     ctx.set_option("pipeline", 3)
     a3, b3 = render_frame(ctx, s, W, H, 4, 8, 0, 2024, 3, 1)
     assert (bits(a1) == bits(a3)).all() and (b1 == b3).all()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    a4, b4 = render_frame(ctx, s, W, H, 4, 8, 0, 2024, 3, 1)
+    assert (bits(a4) == bits(a3)).all() and (b4 == b3).all()
     fb = R.Framebuffer(ctx, W, H)
     for rank in range(8):
         s.render_tasks(fb, 10, rank, 8, 8, None, 3, 4, 2024)
@@ -407,6 +417,10 @@ def test_tall_narrow_and_odd_frames_bins_equal_single_kernel(ctx, mesh, W, H, ns
     ctx.set_option("pipeline", 3)
     a3, b3 = render_frame(ctx, s, W, H, ns, depth, 0, 555, 1, 2)
     assert (bits(a0) == bits(a3)).all() and (b0 == b3).all()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)        # frames that do not tile run through the bins too (partial tiles), no fallback
+    a4, b4 = render_frame(ctx, s, W, H, ns, depth, 0, 555, 1, 2)
+    assert ctx.last_pass_pipeline() == 4
+    assert (bits(a0) == bits(a4)).all() and (b0 == b4).all()
 
 
 @pytest.mark.gpu
@@ -461,7 +475,7 @@ def test_scene_closest_hit_vs_reference_golden(ctx, tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default_nofuzz_d5", "default_preview", "quirk_d4", "quirk_preview", "shapes_d6", "shapes_1spp_d2", "room_d8", "tris_d5"])
-@pytest.mark.parametrize("pipeline", [3, 0])
+@pytest.mark.parametrize("pipeline", [4, 3, 0])
 def test_scene_frame_vs_reference_golden(ctx, name, pipeline):
     """RayTracerProgram::SetupScene's scene (fuzziness zeroed, see tests/scenes.py), the texture-inheritance scene and the
     analytic-only scene: the frames the reference's RayTrace rendered, bit for bit, through the default pipeline and the single kernel."""
@@ -471,8 +485,11 @@ def test_scene_frame_vs_reference_golden(ctx, name, pipeline):
     ctx.set_option("pipeline", pipeline)
     try:
         accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
+        used = ctx.last_pass_pipeline()
     finally:
-        ctx.set_option("pipeline", 3)
+        ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    if pipeline == 4:       # no cliff: texel-inheritance scenes (a textured mesh before an analytic shape) stay in the pass-batched pipeline
+        assert used == 4
     assert (argb == g["argb"]).all()
     if not preview:
         assert (bits(accum) == bits(g["accum"])).all()
@@ -509,10 +526,13 @@ def test_scene_pipelines_agree_at_size(ctx, tag, W, H, ns, depth):
     ctx.set_option("pipeline", 3)
     a3, b3 = render_frame(ctx, s, W, H, ns, depth, 0, 31, 0, 2)
     assert (bits(a0) == bits(a3)).all() and (b0 == b3).all()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    a4, b4 = render_frame(ctx, s, W, H, ns, depth, 0, 31, 0, 2)
+    assert ctx.last_pass_pipeline() == 4
+    assert (bits(a0) == bits(a4)).all() and (b0 == b4).all()
     fb = R.Framebuffer(ctx, W, H)
-    for p in range(2):
-        for rank in range(3):
-            s.render_tasks(fb, 10, rank, 3, depth, None, p, ns, 31)
+    for rank in range(3):
+        s.render_passes(fb, 10, rank, 3, depth, None, 0, 2, ns, 31)
     assert (bits(fb.read_float()) == bits(a3)).all()
 
 
@@ -525,6 +545,7 @@ def test_single_sample_passes_resolved_by_the_shading_lanes_equal_the_resolve_ke
     dealt tasks and graph replay."""
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5))
     out = []
+    ctx.set_option("pipeline", 3)
     for inline in (0, 1):
         ctx.set_option("resolve_inline", inline)
         a, b = render_frame(ctx, s, W, H, 1, depth, preview, 2468, 2, 3)
@@ -533,6 +554,7 @@ def test_single_sample_passes_resolved_by_the_shading_lanes_equal_the_resolve_ke
             s.render_passes(fb, 10, rank, 2, depth, R.RenderOption(bool(preview)), 2, 3, 1, 2468)
         out.append((a, b, fb.read_float(), fb.resolve_argb()))
     ctx.set_option("resolve_inline", 1)
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
     for k in range(4):
         assert (bits(out[0][k]) == bits(out[1][k])).all(), k
     assert (bits(out[1][0]) == bits(out[1][2])).all() and (out[1][1] == out[1][3]).all()
@@ -551,6 +573,7 @@ def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, m
         for p in range(7):
             s.render_tasks(ref, 10, rank, world, depth, None, p, ns, 99)
     ra, rb = ref.read_float(), ref.resolve_argb()
+    ctx.set_option("pipeline", 3)
     for batch in (1, 0):
         ctx.set_option("batch_passes", batch)
         fb = R.Framebuffer(ctx, W, H)
@@ -560,6 +583,7 @@ def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, m
         a, b = fb.read_float(), fb.resolve_argb()
         assert (bits(a) == bits(ra)).all() and (b == rb).all(), batch
     ctx.set_option("batch_passes", 1)
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
 
 
 @pytest.mark.gpu
@@ -580,6 +604,96 @@ def test_last_trace_round_that_finishes_its_paths_equals_a_last_shade_launch(ctx
             ctx.set_option("pipeline", pipeline)
             out.append(render_frame(ctx, s, W, H, ns, depth, 0, 1357, 0, 2))
         ctx.set_option("finish_in_trace", 0)
-        ctx.set_option("pipeline", 3)
+        ctx.set_option("pipeline", DEFAULT_PIPELINE)
         for o in out[1:]:
             assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
+
+
+# ---- the pass-batched pipeline (pipeline 4, the default): K passes share one set of launches ---------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,W,H,ns,depth,world", [("TorusKnot", 1920, 1080, 1, 4, 1), ("unitychan", 640, 360, 4, 4, 2), ("BlenderMonkey", 333, 217, 3, 6, 3),
+                                                     ("TorusKnot", 640, 360, 2, 1, 1), ("BlenderMonkey", 200, 64, 4, 0, 1)])
+def test_k_batched_passes_equal_pass_by_pass(ctx, mesh, W, H, ns, depth, world):
+    """rtw_render_passes renders its passes in groups of K that share one set of launches (K x the rays per launch); every pixel's
+    accumulate + ARGB resolve still runs once per pass in pass order.  For every group size, first pass and split into calls the
+    accumulator and the ARGB image are those of one rtw_render_tasks call per pass through the single kernel (pipeline 0)."""
+    mat = R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5)
+    s = gpu_scene(ctx, mesh, mat)
+    npass, first = 11, 2
+    ctx.set_option("pipeline", 0)
+    ref = R.Framebuffer(ctx, W, H)
+    for rank in range(world):
+        for p in range(first, first + npass):
+            s.render_tasks(ref, 10, rank, world, depth, None, p, ns, 4242)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    try:
+        for gmax, calls in ((64, (11,)), (4, (11,)), (2, (3, 8)), (1, (11,)), (8, (1, 1, 9)), (16, (5, 6))):
+            ctx.set_option("group_max", gmax)
+            fb = R.Framebuffer(ctx, W, H)
+            for rank in range(world):
+                p = first
+                for n in calls:
+                    s.render_passes(fb, 10, rank, world, depth, None, p, n, ns, 4242)
+                    p += n
+            assert ctx.last_pass_pipeline() == 4
+            a, b = fb.read_float(), fb.resolve_argb()
+            assert (bits(a) == bits(ra)).all() and (b == rb).all(), (gmax, calls)
+            fb.close()
+    finally:
+        ctx.set_option("group_max", 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,W,H,ns,depth", [("default_nofuzz", 400, 400, 4, 5), ("quirk", 320, 180, 4, 4), ("room", 256, 256, 2, 6), ("shapes", 333, 211, 4, 6)])
+def test_k_batched_passes_multi_shape_scenes(ctx, tag, W, H, ns, depth):
+    """The same for scenes with spheres / planes / capsules / triangles beside meshes, including the texel-inheritance scene (a textured mesh
+    BEFORE an analytic shape, Src/RRay.cpp:53-58,75-80), which the pass-batched pipeline renders itself (hit records carry the mesh hit whose
+    sampled colour the analytic hit keeps) -- no fallback to the single kernel."""
+    s = multi_scene_gpu(ctx, tag)
+    ctx.set_option("pipeline", 0)
+    ref = R.Framebuffer(ctx, W, H)
+    for p in range(6):
+        R.ThreadWorker_Render(s, ref, 0, W * H - 1, depth, None, p, ns, 99)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    for gmax in (64, 2):
+        ctx.set_option("group_max", gmax)
+        fb = R.Framebuffer(ctx, W, H)
+        s.render_passes(fb, 10, 0, 1, depth, None, 0, 6, ns, 99)
+        assert ctx.last_pass_pipeline() == 4
+        assert (bits(fb.read_float()) == bits(ra)).all() and (fb.resolve_argb() == rb).all(), gmax
+        fb.close()
+    ctx.set_option("group_max", 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4)])
+def test_pass_batched_trace_variants_agree(ctx, mesh, ns, depth):
+    """The trace round's variants -- persistent waves that refill their lanes / plain batches, upper tree levels staged in LDS / read through
+    L2, a wave per ray for short lists, rays that exceed their visit budget handed to the wave-per-ray kernel -- give the same bits (1280x720, 5 passes)."""
+    W, H = 1280, 720
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
+    ref = None
+    try:
+        for persist, stage, below, budget in ((1, 1, 100000, 256), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 8), (1, 1, 100000000, 256), (1, 1, 0, 64)):
+            for k, v in (("trace_persist", persist), ("trace_stage", stage), ("wave_below", below), ("visit_budget", budget)):
+                ctx.set_option(k, v)
+            fb = R.Framebuffer(ctx, W, H)
+            s.render_passes(fb, 10, 0, 1, depth, None, 0, 5, ns, 2025)
+            s.render_passes(fb, 10, 0, 1, depth, None, 5, 5, ns, 2025)       # (the second call knows the first one's list lengths: short lists take the wave-per-ray kernel)
+            out = (fb.read_float(), fb.resolve_argb())
+            fb.close()
+            if ref is None:
+                ref = out
+            else:
+                assert (bits(out[0]) == bits(ref[0])).all() and (out[1] == ref[1]).all(), (persist, stage, below, budget)
+    finally:
+        for k, v in (("trace_persist", 1), ("trace_stage", 1), ("wave_below", 100000), ("visit_budget", 256)):
+            ctx.set_option(k, v)
+    ctx.set_option("pipeline", 0)
+    a0, b0 = R.Framebuffer(ctx, W, H), None
+    for p in range(10):
+        R.ThreadWorker_Render(s, a0, 0, W * H - 1, depth, None, p, ns, 2025)
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    assert (bits(a0.read_float()) == bits(ref[0])).all() and (a0.resolve_argb() == ref[1]).all()

@@ -70,6 +70,10 @@ def material(rng, depth=0):
     return R.SurfaceMaterial_Null()
 
 
+DEFAULTS = dict(pipeline=4, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1,
+                finish_in_trace=0, auto_fused=1, group_max=64, trace_stage=1, trace_persist=1, wave_below=100000, visit_budget=256)
+
+
 def run(seed_arg, cases, ctx=None, log=print):
     rng = np.random.default_rng(seed_arg)
     ctx = ctx or R.Context(0)
@@ -98,18 +102,23 @@ def run(seed_arg, cases, ctx=None, log=print):
         W = int(rng.choice([1, 7, 16, 37, 48, 64, 96, 100, 128, 160, 200, 256, 333, 384, 512, 640, 1024, 1920]))
         H = int(rng.choice([1, 5, 36, 54, 64, 90, 100, 108, 128, 211, 256, 360, 450, 600, 1080]))
         spp, depth = int(rng.integers(1, 5)), int(rng.integers(0, 9))
-        prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 4))
+        prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 6))
         world, rows = int(rng.choice([1, 1, 2, 3, 8])), int(rng.choice([10, 10, 7, 16, 1]))
         opts = dict(direct_slots=int(rng.random() < 0.8), sky_split=int(rng.random() < 0.8), wave_stage=int(rng.choice([0, 0, 0, 1, 2, 3, -1])),
                     trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3), lead_split=int(rng.random() < 0.8), resolve_inline=int(rng.random() < 0.8), batch_passes=int(rng.random() < 0.7), finish_in_trace=int(rng.random() < 0.4), auto_fused=int(rng.random() < 0.7))
+        # the pass-batched pipeline's own switches: passes per group, staging, persistent waves, the wave-per-ray threshold, the visit budget
+        gopts = dict(group_max=int(rng.choice([1, 2, 4, 64])), trace_stage=int(rng.random() < 0.7), trace_persist=int(rng.random() < 0.7),
+                     wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 256])), sky_split=opts["sky_split"])
         res = []
-        for pl in (0, 3):
+        for pl in (0, 3, 4):
             ctx.set_option("pipeline", pl)
             for k, v in opts.items():
-                ctx.set_option(k, v if pl == 3 else dict(direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1, finish_in_trace=0, auto_fused=1)[k])
+                ctx.set_option(k, v if pl == 3 else DEFAULTS[k])
+            for k, v in gopts.items():
+                ctx.set_option(k, v if pl == 4 else DEFAULTS[k])
             fb = R.Framebuffer(ctx, W, H)
             for rank in range(world):
-                if pl == 3 and (opts["use_graph"] or opts["batch_passes"]):
+                if (pl == 3 and (opts["use_graph"] or opts["batch_passes"])) or (pl == 4 and rng.random() < 0.8):
                     s.render_passes(fb, rows, rank, world, depth, R.RenderOption(bool(prev)), 0, npass, spp, seed)
                 else:
                     for p in range(npass):
@@ -117,10 +126,10 @@ def run(seed_arg, cases, ctx=None, log=print):
             res.append((fb.read_float().view(np.uint32).copy(), fb.resolve_argb().copy()))
             fb.close()
         s.close()
-        ok = bool((res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all())
+        ok = all(bool((res[0][0] == r[0]).all() and (res[0][1] == r[1]).all()) for r in res[1:])
         bad += not ok
-        log(it, kind, W, H, "spp", spp, "d", depth, "prev", prev, "passes", npass, "world", world, "rows", rows, opts, "OK" if ok else "DIFF", flush=True)
-    for k, v in dict(pipeline=3, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1, finish_in_trace=0, auto_fused=1).items():
+        log(it, kind, W, H, "spp", spp, "d", depth, "prev", prev, "passes", npass, "world", world, "rows", rows, opts, gopts, "OK" if ok else "DIFF", flush=True)
+    for k, v in DEFAULTS.items():
         ctx.set_option(k, v)
     log("soak done, seed", seed_arg, "mismatches:", bad)
     return bad
