@@ -34,6 +34,7 @@
 #undef private
 #undef protected
 #include "Math.h"
+#include "Texture.h"
 #include "ColorBuffer.h"
 #include "ThreadTaskQueue.h"
 #include "rt_oracle.h"   // only for the orc_material_node layout
@@ -56,7 +57,9 @@ static inline uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample)
 static const uint32_t kTableSize = 0xFFFFFFu, kTableStride = 16u, kTableSeed = 0x52544142u;
 static inline uint32_t table_phase(uint32_t seed) { return mix32(seed ^ 0x7AB1E5u) % kTableSize; }
 
-enum RandMode { RM_ZERO, RM_KEYED, RM_THREAD_LOCAL, RM_GLIBC_LIKE };
+enum RandMode { RM_ZERO, RM_KEYED, RM_THREAD_LOCAL, RM_GLIBC_LIKE, RM_RECORD, RM_SCRIPT };
+static std::vector<int> g_script;      // RM_RECORD: the keyed stream's values in call order; RM_SCRIPT: played back to the reference's own loop
+static size_t g_script_pos = 0;
 static RandMode g_mode = RM_ZERO;
 static thread_local uint32_t t_key = 0, t_counter = 0;
 static thread_local uint64_t t_xs = 0x9E3779B97F4A7C15ull;
@@ -68,6 +71,11 @@ extern "C" int rand(void)
     switch (g_mode) {
     case RM_ZERO: return 0;
     case RM_KEYED: return (int)(mix32(t_key + t_counter++) >> 1);
+    case RM_RECORD: { const int v = (int)(mix32(t_key + t_counter++) >> 1); g_script.push_back(v); return v; }
+    case RM_SCRIPT: {
+        if (g_script_pos >= g_script.size()) { fprintf(stderr, "harness: the reference's loop drew more numbers than the recorded pass\n"); exit(6); }
+        return g_script[g_script_pos++];
+    }
     case RM_THREAD_LOCAL: {
         t_xs ^= t_xs << 13; t_xs ^= t_xs >> 7; t_xs ^= t_xs << 17;
         return (int)((t_xs >> 33) & 0x7FFFFFFF);
@@ -241,6 +249,7 @@ static void dump_tree(const KdNode* n, std::vector<float>& bounds, std::vector<i
 // camera loop of ThreadWorker_Render with run-time W/H and ns sub-samples
 struct FrameParams { int W, H, ns, depth, preview; uint32_t seed; };
 
+static bool g_no_table = false;     // the scene's materials never read the unit-vector table (preview, mirrors): leave the cursor alone
 static RVec3 render_pixel(const FrameParams& fp, int PixelIndex, int pass, bool keyed)
 {
     const RVec3 ViewPoint(0, 0, 7.0f);
@@ -262,7 +271,7 @@ static RVec3 render_pixel(const FrameParams& fp, int PixelIndex, int pass, bool 
         if (keyed) {
             set_key(path_key(fp.seed, (uint32_t)PixelIndex, (uint32_t)(pass * 4 + i)));
             base = (((uint64_t)pass * npix + (uint64_t)PixelIndex) * 4u + (uint64_t)i) * kTableStride + phase;
-            cursor_advance_to(base);
+            if (!g_no_table) cursor_advance_to(base);
         }
         float offset_x = ox[i];
         float offset_y = oy[i];
@@ -271,13 +280,20 @@ static RVec3 render_pixel(const FrameParams& fp, int PixelIndex, int pass, bool 
         RVec3 Dir(dx + offset_x, dy + offset_y, -0.5f);
         RRay ray(ViewPoint, Dir.GetNormalizedVec3(), 1000.0f);
         c += Scene->RayTrace(ray, fp.depth, opt);
-        if (keyed) cursor_relocate(base);
+        if (keyed && !g_no_table) cursor_relocate(base);
     }
     c /= (float)fp.ns;
     return c;
 }
 
 struct AccPixel { RVec3 sum; int n; };
+
+// The reference's own pixel-range worker and the buffers it writes (external linkage, Src/RayTracerProgram.cpp:49,77,131).
+// AccumulatePixel is defined in that .cpp only; this declaration has its two data members in the same order (16 bytes).
+void ThreadWorker_Render(int begin, int end, int MaxBounceCount, const RenderOption& InOption);
+extern Pixel bitcolor[];
+struct AccumulatePixel { RVec3 AccumulatedColor; int Num; };
+extern AccumulatePixel accuBuffer[];
 
 struct TimeTask { int Start, End; };
 typedef ThreadTaskQueue<TimeTask> TimeQueue;
@@ -484,6 +500,52 @@ int main(int argc, char** argv)
                threads, passes, row1 - row0, (long long)(row1 - row0) * fp.W, best, total / passes, argv[10], chk);
         return 0;
     }
+
+    // worker OBJ MAT DEPTH PREVIEW SEED PASS0 NPASS BEGIN END OUT
+    // The reference's OWN ThreadWorker_Render (800 x 800, four sub-samples: compile-time constants) over pixels BEGIN..END for NPASS
+    // passes, writing its own accuBuffer[] / bitcolor[].  The loop cannot be told which (pixel, sample) it is at, so each pass is
+    // first run through this file's restatement with the keyed generator RECORDING every value rand() returns, and the reference's
+    // loop then gets exactly that sequence played back; it must consume it to the last number.  Only for scenes whose materials never
+    // read the unit-vector table (a preview pass, mirrors): that table's cursor cannot be set from inside the reference's loop.
+    if (cmd == "worker" && argc == 12) {
+        setup_scene(argv[2], argv[3]);
+        FrameParams fp; fp.W = bitmapWidth; fp.H = bitmapHeight; fp.ns = 4; fp.depth = atoi(argv[4]);
+        fp.preview = atoi(argv[5]); fp.seed = (uint32_t)strtoul(argv[6], nullptr, 0);
+        int pass0 = atoi(argv[7]), npass = atoi(argv[8]), begin = atoi(argv[9]), end = atoi(argv[10]);
+        if (begin < 0 || end >= bitmapWidth * bitmapHeight || end < begin) { fprintf(stderr, "harness: bad range\n"); return 2; }
+        RenderOption opt; opt.UseBaseColor = fp.preview != 0;
+        g_no_table = true;
+        double restated = 0;
+        for (int pass = pass0; pass < pass0 + npass; pass++) {
+            g_script.clear(); g_script_pos = 0;
+            g_mode = RM_RECORD;
+            for (int p = begin; p <= end; p++) { RVec3 c = render_pixel(fp, p, pass, true); restated += c.x; }
+            g_mode = RM_SCRIPT;
+            ThreadWorker_Render(begin, end, fp.depth, opt);
+            if (g_script_pos != g_script.size()) { fprintf(stderr, "harness: the reference's loop drew %zu numbers, the recorded pass %zu\n", g_script_pos, g_script.size()); return 6; }
+        }
+        g_mode = RM_ZERO;
+        const size_t n = (size_t)(end - begin + 1);
+        std::vector<float> out(n * 4);
+        for (size_t i = 0; i < n; i++) {
+            const AccumulatePixel& a = accuBuffer[(size_t)begin + i];
+            out[i * 4] = a.AccumulatedColor.x; out[i * 4 + 1] = a.AccumulatedColor.y; out[i * 4 + 2] = a.AccumulatedColor.z; out[i * 4 + 3] = (float)a.Num;
+        }
+        std::string o = argv[11];
+        write_file(o + ".accum.f32", out.data(), out.size() * 4);
+        write_file(o + ".argb.u32", &bitcolor[begin], n * sizeof(Pixel));
+        return 0;
+    }
+
+    // savepng ARGB W H OUT.png : RTexture::SaveBufferToPNG (Src/Texture.cpp:201-283) of a 0xAARRGGBB buffer
+    if (cmd == "savepng" && argc == 6) {
+        const int w = atoi(argv[3]), h = atoi(argv[4]);
+        auto px = read_file<uint32_t>(argv[2], (size_t)w * h);
+        return RTexture::SaveBufferToPNG(argv[5], px.data(), w, h) ? 0 : 7;
+    }
+
+    // timestring MS... : RayTracerProgram's FormatTimeString through a progress line is not reachable from outside (a static function);
+    // see tests/test_facade_cpp.py for the format pinned from the source text.
 
     fprintf(stderr, "ref_harness: bad command line\n");
     return 1;

@@ -126,6 +126,32 @@ def golden_frame(tag, name, mat, W, Hh, ns, depth, preview, seed, pass0, npass, 
                         argb=np.fromfile(fp + ".argb.u32", np.uint32))
 
 
+def golden_worker(tag, name, mat, depth, preview, seed, pass0, npass, tmp):
+    """The reference's OWN ThreadWorker_Render (Src/RayTracerProgram.cpp:131-188; 800 x 800, 4 sub-samples) writing its own accuBuffer[] /
+    bitcolor[] (harness command `worker`).  Kept: the whole ARGB image, the SHA-256 of the accumulator's bytes (count as int32) and the
+    accumulator of a 64-row band."""
+    import hashlib
+    W = Hh = 800
+    arr = O.materials(MATERIALS[mat])
+    mp, fp = os.path.join(tmp, "mat.bin"), os.path.join(tmp, "worker")
+    arr.tofile(mp)
+    run(["worker", obj_path(name), mp, depth, preview, seed, pass0, npass, 0, W * Hh - 1, fp])
+    accum = np.fromfile(fp + ".accum.f32", np.float32).reshape(-1, 4)
+    ints = accum.copy()
+    ints[:, 3] = accum[:, 3].astype(np.int32).view(np.float32)          # the count as the int the reference holds
+    band = slice(368 * W, 432 * W)
+    np.savez_compressed(os.path.join(OUT, "worker_%s.npz" % tag), mesh=name, material=arr,
+                        params=np.array([W, Hh, 4, depth, preview, seed, pass0, npass], np.int64),
+                        argb=np.fromfile(fp + ".argb.u32", np.uint32), accum_sha256=hashlib.sha256(ints.tobytes()).hexdigest(),
+                        band=np.array([368, 432], np.int64), accum_band=accum[band])
+
+
+def main_worker(tmp):
+    golden_worker("torus_mirror_d4", "TorusKnot", "mirror", 4, 0, 31, 0, 2, tmp)
+    golden_worker("unitychan_preview", "unitychan", "diffuse", 4, 1, 31, 0, 1, tmp)
+    golden_worker("unitychan_mirror_d3", "unitychan", "mirror", 3, 0, 77, 1, 1, tmp)
+
+
 def golden_raytrace(tag, name, mat, n, depth, seed, W, Hh, tmp, rng, bounds):
     rays = make_rays(bounds, n, rng)
     keys = np.c_[rng.integers(0, W * Hh, len(rays)), rng.integers(0, 8, len(rays))].astype(np.uint32)
@@ -208,6 +234,10 @@ def main():
     if not os.path.exists(H):
         sys.exit("oracle/_ref/ref_harness is not built (no /root/reference here?)")
     rng = np.random.default_rng(20261004)
+    if "--worker-only" in sys.argv:        # add the ThreadWorker_Render fixtures without regenerating the others
+        with tempfile.TemporaryDirectory() as tmp:
+            main_worker(tmp)
+        return
     if "--scenes-only" in sys.argv:        # add the multi-shape fixtures without regenerating the others
         rng = np.random.default_rng(20261005)
         with tempfile.TemporaryDirectory() as tmp:
@@ -239,6 +269,7 @@ def main():
         golden_raytrace("unitychan_diffuse", "unitychan", "diffuse", 500, 6, 4242, 1920, 1080, tmp, rng, bounds["unitychan"])
         golden_raytrace("monkey_blendfuzz", "BlenderMonkey", "blendfuzz", 900, 6, 4242, 1920, 1080, tmp, rng, bounds["BlenderMonkey"])
         main_scenes(tmp, np.random.default_rng(20261005), bounds)
+        main_worker(tmp)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("golden fixtures written: %.2f MB" % (total / 1e6))
 

@@ -697,3 +697,32 @@ def test_pass_batched_trace_variants_agree(ctx, mesh, ns, depth):
         R.ThreadWorker_Render(s, a0, 0, W * H - 1, depth, None, p, ns, 2025)
     ctx.set_option("pipeline", DEFAULT_PIPELINE)
     assert (bits(a0.read_float()) == bits(ref[0])).all() and (a0.resolve_argb() == ref[1]).all()
+
+
+WORKERS = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN, "worker_*.npz")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", WORKERS)
+def test_frame_vs_the_references_own_thread_worker_render(ctx, tag):
+    """The GPU frame against what the reference's OWN ThreadWorker_Render wrote into its accuBuffer[] / bitcolor[] (800 x 800, 4 sub-samples,
+    its compiled-in constants; fixtures worker_*.npz): ARGB for every pixel, the accumulator through its SHA-256 and a 64-row band, bit for bit.
+    Passes rendered one call each and as one K-batched rtw_render_passes call."""
+    from test_oracle_golden import worker_digest
+    g = np.load(os.path.join(GOLDEN, "worker_%s.npz" % tag))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    s = gpu_scene(ctx, str(g["mesh"]), R.material_nodes_from_array(g["material"]))
+    for batched in (False, True):
+        fb = R.Framebuffer(ctx, W, H)
+        if batched:
+            s.render_passes(fb, 10, 0, 1, depth, R.RenderOption(bool(preview)), pass0, npass, ns, seed)
+        else:
+            for p in range(pass0, pass0 + npass):
+                R.ThreadWorker_Render(s, fb, 0, W * H - 1, depth, R.RenderOption(bool(preview)), p, ns, seed)
+        accum, argb = fb.read_float(), fb.resolve_argb()
+        fb.close()
+        assert (argb == g["argb"]).all()
+        if not preview:
+            r0, r1 = [int(v) for v in g["band"]]
+            assert (bits(accum[r0 * W:r1 * W]) == bits(g["accum_band"])).all()
+            assert worker_digest(accum) == str(g["accum_sha256"])

@@ -176,3 +176,37 @@ def test_scene_frame_matches_reference(oracle_mod, name):
     assert (argb == g["argb"]).all()
     if not preview:         # a preview pass writes the picture only
         assert (bits(accum) == bits(g["accum"])).all()
+
+
+WORKERS = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN, "worker_*.npz")))
+
+
+def worker_digest(accum):
+    """SHA-256 of an accumulator as the reference holds it: three floats + the int32 count per pixel"""
+    import hashlib
+    ints = np.ascontiguousarray(accum, np.float32).copy()
+    ints[:, 3] = ints[:, 3].astype(np.int32).view(np.float32)
+    return hashlib.sha256(ints.tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("tag", WORKERS)
+def test_oracle_vs_the_references_own_thread_worker_render(oracle_mod, tag):
+    """worker_*.npz hold what the reference's OWN ThreadWorker_Render (Src/RayTracerProgram.cpp:131-188, not the harness's restatement of
+    it) left in its accuBuffer[] / bitcolor[] at its compiled-in 800 x 800: the oracle's pixel loop, accumulation, gamma and packing
+    (rows a1-a3 of SURVEY.md 8a) against that, bit for bit."""
+    O = oracle_mod
+    g = np.load(os.path.join(GOLDEN, "worker_%s.npz" % tag))
+    W, H, ns, depth, preview, seed, pass0, npass = [int(v) for v in g["params"]]
+    assert (W, H, ns) == (800, 800, 4)
+    s = O.Scene()
+    sh = s.add_mesh_obj(asset(str(g["mesh"]) + ".obj"))
+    s.set_material(sh, g["material"])
+    fb = O.Framebuffer(W, H)
+    for p in range(pass0, pass0 + npass):
+        s.render_pass_pool(fb, depth, bool(preview), p, ns, seed, threads=0, task_rows=10)
+    accum, argb = fb.read()
+    assert (argb == g["argb"]).all()
+    if not preview:
+        r0, r1 = [int(v) for v in g["band"]]
+        assert (bits(accum[r0 * W:r1 * W]) == bits(g["accum_band"])).all()
+        assert worker_digest(accum) == str(g["accum_sha256"])
