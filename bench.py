@@ -12,9 +12,12 @@ For N>1 the SAME frame is split into the reference's 10-row tasks dealt round-ro
 RCCL once, inside the timed region, after the K passes (the reference also writes its image once,
 after all passes).  Inputs are resident in HBM before the timed region starts.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the render kernel against HBM with ALGORITHMIC
-bytes from reference-faithful visit counters; `cpu_baseline` times the reference's CPU path
-(oracle/_ref, the reference's own sources) or the oracle port on the host cores.
+`--config c5` is BASELINE configs[4] (unitychan, 3840x2160, depth 8; a step = one 4-spp pass of its 16 spp).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the render pass against HBM with SURVEY.md 8(d)'s
+algorithmic bytes (executed tests; the reference-order figure and the rocprof-measured traffic beside
+it); `cpu_baseline` times the reference's CPU path (oracle/_ref, the reference's own sources) or the
+oracle port on the host cores.
 """
 import argparse
 import json
@@ -34,6 +37,8 @@ CONFIGS = {
     "c2": ("TorusKnot", 1920, 1080, 1, 4, "diffuse"),
     "c3": ("BlenderMonkey", 1920, 1080, 4, 6, "blend"),
     "c4": ("unitychan", 1920, 1080, 4, 4, "diffuse"),
+    # BASELINE configs[4]: 16 spp = four passes of four sub-samples; `--gpus 8` splits the frame over 8 ranks + one gather
+    "c5": ("unitychan", 3840, 2160, 4, 8, "diffuse"),
     # RayTracerProgram::SetupScene (4 spheres, capsule, ground plane, unitychan) at the reference's window size and bounce limit
     "setup": ("unitychan", 800, 800, 4, 10, "setup"),
 }
@@ -79,12 +84,11 @@ def oracle_material(O, kind):
     return [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)]
 
 
-def algorithmic_bytes(st, pixels):
-    """Bytes one launch must touch with the layout the kernel fetches ('Roofline'):
-    32 B per node visit, 64 B per triangle record, 140 B per shaded hit (64 B shading record + 64 B
-    triangle record re-read + 12 B unit-vector entry), 16 B per bilinear texture sample (4 RGBA8
-    texels), 36 B per pixel (16 B accumulator read + 16 B write + 4 B ARGB)."""
-    return 32 * st["box_tests"] + 64 * st["tri_tests"] + 140 * st["shaded_hits"] + 16 * st["tex_samples"] + 36 * pixels
+def algorithmic_bytes(st, pixel_passes, texel_bytes=4):
+    """B = 32 V + 48 T + 64 H + 4 * texel_bytes * S + 36 P -- V box tests (32 B node), T triangle tests (three 12-B positions
+    padded to 48), H shaded hits (three normals + three uv + material id ~ 64 B), S bilinear texture samples (four texels each; RGBA8 here),
+    P pixel-passes (16 B accumulator read + 16 B write + 4 B ARGB)."""
+    return 32 * st["box_tests"] + 48 * st["tri_tests"] + 64 * st["shaded_hits"] + 4 * texel_bytes * st["tex_samples"] + 36 * pixel_passes
 
 
 def oracle_nodes(O, m):
@@ -147,7 +151,9 @@ def cpu_baseline_setup(mesh_path, W, H, spp, depth, rays_per_frame, budget_s):
 
 
 def cpu_baseline(mesh_path, W, H, spp, depth, kind, rays_per_frame, budget_s=20.0):
-    """The reference's CPU path on the host cores, bounded to roughly `budget_s` seconds of wall time."""
+    """The reference's CPU path on the host cores, bounded to roughly `budget_s` seconds of wall time: the reference's own translation
+    units (oracle/_ref) through its ThreadTaskQueue with a per-thread rand() ("CPU ref"), and once more with a process-wide lock per rand()
+    call like glibc's ("reference as shipped")."""
     from oracle import oracle as O
     if kind == "setup":
         return cpu_baseline_setup(mesh_path, W, H, spp, depth, rays_per_frame, budget_s)
@@ -157,14 +163,21 @@ def cpu_baseline(mesh_path, W, H, spp, depth, kind, rays_per_frame, budget_s=20.
         with tempfile.TemporaryDirectory() as tmp:
             mp = os.path.join(tmp, "mat.bin")
             O.materials(oracle_material(O, kind)).tofile(mp)
-            probe = json.loads(subprocess.check_output([harness, "time", mesh_path, mp, str(W), str(H), str(spp), str(depth),
-                                                        str(cores), "1", "tl"], stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
-            passes = int(max(2, min(200, budget_s / max(probe["mean_s"] + 1.5 / max(1, 200), 1e-3) * 0.5)))
+            run = lambda passes, mode: json.loads(subprocess.check_output([harness, "time", mesh_path, mp, str(W), str(H), str(spp), str(depth),  # noqa: E731
+                                                                           str(cores), str(passes), mode], stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            probe = run(1, "tl")
             # the harness spends ~1.3 s filling the unit-vector table before timing; bounded passes after it
-            res = json.loads(subprocess.check_output([harness, "time", mesh_path, mp, str(W), str(H), str(spp), str(depth),
-                                                      str(cores), str(passes), "tl"], stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            passes = int(max(2, min(200, budget_s * 0.7 / max(probe["mean_s"], 1e-3) * 0.5)))
+            res = run(passes, "tl")
+            shipped = None
+            try:
+                sp = run(1, "glibc")
+                shipped = {"ms_per_frame": sp["mean_s"] * 1e3, "Mrays_per_s": rays_per_frame / sp["mean_s"] / 1e6,
+                           "sample": "1 full %dx%d pass, one process-wide lock per rand() call like glibc's rand() (the reference as shipped does not scale with cores)" % (W, H)}
+            except Exception:
+                shipped = None
         return {"value": rays_per_frame / res["mean_s"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
-                "ms_per_frame": res["mean_s"] * 1e3,
+                "ms_per_frame": res["mean_s"] * 1e3, "as_shipped_glibc_rand": shipped,
                 "sample": "%d full %dx%d passes of the reference's own translation units (oracle/_ref: RayTrace + "
                           "ThreadTaskQueue.h, 10-row tasks, per-thread rand()); rays/frame taken from the GPU counters "
                           "of the same frame" % (passes, W, H)}
@@ -185,19 +198,41 @@ def cpu_baseline(mesh_path, W, H, spp, depth, kind, rays_per_frame, budget_s=20.
             "sample": "%d full %dx%d passes of the oracle port (recursive pointer tree, un-pruned DFS, 10-row task pool)" % (passes, W, H)}
 
 
+def rays_through_shape_boxes(scene, W, H, spp):
+    """How many camera rays (pixel-centre directions; the sub-sample jitter moves a ray by less than half a pixel) meet the culling box of
+    some shape of the scene: the 'non-trivial' camera rays.  Host arithmetic on the shapes' bounds, outside the timed region."""
+    xs = np.arange(W, dtype=np.float64)
+    ys = np.arange(H, dtype=np.float64)
+    dx = -(xs - W // 2) / (W * 2) * (W / H)
+    dy = -(ys - H // 2) / (H * 2)
+    d = np.stack(np.broadcast_arrays(dx[None, :], dy[:, None], np.full((H, W), -0.5)), -1).reshape(-1, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.array([0.0, 0.0, 7.0])
+    hit = np.zeros(len(d), bool)
+    for k in range(scene.n_shapes):
+        b = scene.mesh_info(k)["bounds"].astype(np.float64)
+        if not np.isfinite(b).all() or (b[3:] < b[:3]).any():
+            return W * H * spp            # a shape without a culling box (a plane): every ray is tested against it
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t1 = (b[:3] - o) / d
+            t2 = (b[3:] - o) / d
+        hit |= np.minimum(t1, t2).max(1) < np.maximum(t1, t2).min(1)
+    return int(hit.sum()) * spp
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--prune", type=int, default=1)
-    ap.add_argument("--pipeline", type=int, default=3)
-    ap.add_argument("--traversal", type=int, default=1)
-    ap.add_argument("--packets", type=int, default=1)
-    ap.add_argument("--path-lanes", type=int, default=16)
-    ap.add_argument("--path-variant", type=int, default=2)
+    ap.add_argument("--pipeline", type=int, default=4)
+    ap.add_argument("--group-max", type=int, default=0, help="passes per group of the pass-batched pipeline (0 = the library's choice)")
+    ap.add_argument("--option", action="append", default=[], help="name=value context option (experiments)")
     ap.add_argument("--depth", type=int, default=0, help="override the config's depth (experiments only)")
+    ap.add_argument("--gather", default="native", choices=("native", "torch"), help="N>1: rtw_gather_rows (RCCL send/recv out of the framebuffers) or torch.distributed.gather")
+    ap.add_argument("--argb-only", action="store_true", help="N>1: gather the displayable image only (4 B/pixel)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -236,9 +271,11 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = R.Context(local_rank, stream=stream.cuda_stream)
     ctx.set_option("pipeline", args.pipeline)
-    ctx.set_option("packets", args.packets)
-    ctx.set_option("path_lanes", args.path_lanes)
-    ctx.set_option("path_variant", args.path_variant)
+    if args.group_max > 0:
+        ctx.set_option("group_max", args.group_max)
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     scene = R.RayTracerScene(ctx)
     if kind == "setup":
         from raytracerwin_amd.setup_scene import SetupScene
@@ -246,8 +283,9 @@ def main():
     else:
         scene.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
     scene.set_prune(args.prune)
-    scene.set_traversal(args.traversal)
-    scene.commit()
+    t0 = time.perf_counter()
+    scene.commit()              # OBJ already parsed: the reference's tree (KdNode::Build's decisions), its flat / explicit-link copies, upload
+    commit_ms = (time.perf_counter() - t0) * 1e3
 
     with torch.cuda.stream(stream):
         accum = torch.zeros(npix * 4, dtype=torch.float32, device=dev)
@@ -255,11 +293,33 @@ def main():
     fb = R.Framebuffer(ctx, W, H, accum.data_ptr(), argb.data_ptr())
 
     from raytracerwin_amd import sharding
+    comm = None
+    gather_kind = None
+    if world > 1 and args.gather == "native":
+        def bootstrap(ident):       # rank 0's ncclUniqueId to every rank, through the process group the launcher set up
+            t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().tolist())
+        try:
+            comm = R.Comm(ctx, rank, world, bootstrap)
+            gather_kind = "rtw_gather_rows: grouped ncclSend / ncclRecv of every rank's task rows straight out of the framebuffers (RCCL over xGMI)"
+        except Exception as e:      # a broken RCCL bootstrap must not lose the measurement: the torch gather does the same exchange
+            comm = None
+            gather_kind = "torch.distributed.gather (rtw_comm_create failed: %r)" % (e,)
+    elif world > 1:
+        gather_kind = "torch.distributed.gather with staging copies"
 
     def steps(first, n):
         # n steps = n passes of the reference's sample loop (UpdateBitmapPixels, Src/RayTracerProgram.cpp:317-361) over this rank's
-        # 10-row tasks: one rtw_render_passes call, pass indices first .. first + n - 1
+        # 10-row tasks: ONE rtw_render_passes call, pass indices first .. first + n - 1 (rendered in groups that share launches)
         scene.render_passes(fb, TASK_ROWS, rank, world, depth, None, first, n, spp, SEED)
+
+    def gather():
+        if comm is not None:
+            comm.gather_rows(fb, TASK_ROWS, args.argb_only)
+        else:
+            bufs = [argb.view(H, W)] if args.argb_only else [accum.view(H, W * 4), argb.view(H, W)]
+            sharding.gather_rows(bufs, H, TASK_ROWS, rank, world, dist, dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -269,26 +329,36 @@ def main():
 
     K, Wm = args.steps, args.warmup
     with torch.cuda.stream(stream):
-        steps(0, Wm)
+        t0 = time.perf_counter()
+        steps(0, 1)             # first use of this frame shape: the screen bins and the tile / job tables are built here (host) and uploaded
+        torch.cuda.synchronize(dev)
+        first_call_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        steps(1, 1)
+        torch.cuda.synchronize(dev)
+        second_call_ms = (time.perf_counter() - t0) * 1e3
+        if Wm > 0:
+            steps(2, Wm)
+        if world > 1:
+            gather()            # RCCL sets its channels up on first use
     barrier()
     accum.zero_()
     argb.zero_()
     barrier()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    gathered = None
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
         steps(0, K)
         ev1.record(stream)
         if world > 1:
-            # the one exchange of the path: every rank's rows of (accumulator, ARGB) to rank 0 over RCCL
-            sharding.gather_rows([accum.view(H, W * 4), argb.view(H, W)], H, TASK_ROWS, rank, world, dist, dev)
-            gathered = True
+            gather()            # the one exchange of the path: every rank's rows to rank 0, once, after the K passes
+        ev2.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K           # HIP events on the launch stream: average render-kernel duration
+    kernel_ms = ev0.elapsed_time(ev1) / K           # HIP events on the launch stream around the K steps: average render-pass duration
+    gather_ms = ev1.elapsed_time(ev2) if world > 1 else None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -296,34 +366,28 @@ def main():
 
     result = None
     if rank == 0:
-        final_accum = accum.cpu().numpy().view(np.uint32).copy()
-        final_argb = argb.cpu().numpy().copy()
-        # untimed replay on one GPU: exact work counters of the K timed passes and the reference image for N>1
-        ctx.stats_enable(True)
-        ctx.stats_reset()
+        final_accum = accum.cpu().numpy().view(np.uint32).reshape(-1, 4).copy()
+        final_argb = argb.cpu().numpy().view(np.uint32).copy()
+        # ---- untimed: the same K passes once more on this GPU alone, pass by pass through the single kernel (pipeline 0, one thread per pixel):
+        # the timed buffers must hold exactly these bits (N = 1 and N > 1 alike)
         fb2 = R.Framebuffer(ctx, W, H)
+        ctx.set_option("pipeline", 0)
         for i in range(K):
             R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, i, spp, SEED)
-        st = ctx.stats()
-        verified = None
-        if world > 1:
-            a2 = fb2.read_float()
-            a2[:, 3] = a2[:, 3].astype(np.int32).view(np.float32)      # count back to int bits
-            verified = bool((a2.view(np.uint32).ravel() == final_accum).all() and (fb2.resolve_argb().view(np.int32) == final_argb).all())
-        # per-kernel durations: HIP events recorded by the library on the launch stream around the three kernels of
-        # a pass (untimed extra passes on the scratch framebuffer; the timed region above stays exactly K steps)
-        ctx.stats_enable(False)
-        ctx.set_option("kernel_timing", 1)
-        kms = []
-        if args.pipeline >= 1:
-            for i in range(30):
-                R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, K + i, spp, SEED)
-                if i >= 5:
-                    kms.append(ctx.last_pass_kernel_ms())
-        ctx.set_option("kernel_timing", 0)
+        a2 = fb2.read_float()
+        a2[:, 3] = a2[:, 3].astype(np.int32).view(np.float32)      # count back to int bits
+        b2 = fb2.resolve_argb()
+        ctx.set_option("pipeline", args.pipeline)
+        same_argb = bool((b2 == final_argb).all())
+        same_accum = bool((a2.view(np.uint32) == final_accum).all()) if not (world > 1 and args.argb_only) else None
+        verified = bool(same_argb and same_accum is not False)
+        # ---- work counters of the K timed passes as the timed pipeline runs them (one GPU, same grouping)
         ctx.stats_enable(True)
-        kernel_parts = [float(np.mean([k[j] for k in kms])) for j in range(3)] if kms else None
-        # reference-faithful visit counts (un-pruned order) of ONE pass for the algorithmic byte count
+        ctx.stats_reset()
+        fb2.clear()
+        scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, 0, K, spp, SEED)
+        st = ctx.stats()
+        # reference-faithful visit counts (un-pruned DFS order: what KdNode::TestRayIntersection visits) of ONE pass
         scene.set_prune(0)
         scene.set_traversal(0)
         ctx.stats_reset()
@@ -331,31 +395,43 @@ def main():
         R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, 0, spp, SEED)
         st_ref = ctx.stats()
         scene.set_prune(args.prune)
-        scene.set_traversal(args.traversal)
-        ctx.stats_reset()
-        R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, 0, spp, SEED)
-        st_run = ctx.stats()
+        scene.set_traversal(1)
         ctx.stats_enable(False)
+        # ---- per-stage durations: HIP events recorded by the library on the launch stream around the stages of one group (extra untimed passes)
+        stage_ms = None
+        if args.pipeline >= 3:
+            ctx.set_option("kernel_timing", 1)
+            acc = []
+            for i in range(3):
+                fb2.clear()
+                scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, 0, min(K, 64), spp, SEED)
+                if i > 0:
+                    acc.append(ctx.last_pass_kernel_ms())
+            ctx.set_option("kernel_timing", 0)
+            g = float(min(K, 64))
+            stage_ms = {"passes_in_the_timed_group": int(g), "primary_per_pass": float(np.mean([k[0] for k in acc])) / g,
+                        "bounce_rounds_per_pass": float(np.mean([k[1] for k in acc])) / g, "resolve_per_pass": float(np.mean([k[2] for k in acc])) / g,
+                        "note": "events between the stages of the LAST group of a call; a call of K passes is rendered in groups of at most 64 passes"}
         fb2.close()
 
         rays_total = st["rays"]
         value = rays_total / elapsed / 1e6
-        alg_bytes = algorithmic_bytes(st_ref, npix) / world
-        run_bytes = algorithmic_bytes(st_run, npix) / world
-        # the three launches of one rtw_render_* call are priced together ("render pass"); at N=1 their event
-        # durations are summed, for N>1 the whole-loop event time per step is used
-        # "launch duration" of a render pass = HIP events on the launch stream around the K timed steps, divided by K
-        # (the pass is several dependent launches; the per-stage event durations below are reported beside it -- recording
-        # events between the stages perturbs them, so their sum is not used)
+        cam_total = st["camera_rays"]
+        nontrivial_cam = rays_through_shape_boxes(scene, W, H, spp)
+        nontrivial = nontrivial_cam * K + (rays_total - cam_total)          # every secondary ray starts on a surface, inside its shape's box
+        st_run_pass = {k: v / K for k, v in st.items()}
+        # bytes per pass: SURVEY.md 8(d)'s weights on (a) the visits the reference's un-pruned walk makes, (b) the tests the timed kernels execute
+        alg_ref = algorithmic_bytes(st_ref, npix)
+        alg_run = algorithmic_bytes(st_run_pass, npix)
         pass_ms = kernel_ms
-        achieved = alg_bytes / (pass_ms * 1e-3) / 1e9
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        tp = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % args.config)
         if os.path.exists(tp) and world == 1:
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("hbm_bytes_per_pass")
             except Exception:
                 traffic = None
+        achieved = alg_run / world / (pass_ms * 1e-3) / 1e9
         result = {
             "metric": "Mrays/s (rays = closest-hit scene queries, primary + secondary) at %dx%d depth %d" % (W, H, depth),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -363,24 +439,43 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": data,
             "config": {"workload": ("RayTracerProgram::SetupScene (4 spheres, capsule, ground plane, %s.obj) %dx%d %d spp depth %d, reference camera "
                                     "(the reference's default scene and window; not a BASELINE config)" % (mesh, W, H, spp, depth)) if kind == "setup" else
-                                   "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s])"
-                                   % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3}[args.config]),
-                       "sharding": "10-row tasks round-robin over ranks, one RCCL gather of the rows after the K passes",
-                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "traversal": args.traversal, "packets": args.packets, "path_lanes": args.path_lanes},
-            "camera_Mrays_per_s": st["camera_rays"] / elapsed / 1e6,
+                                   "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s]%s)"
+                                   % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[args.config],
+                                      "; a step is one 4-spp pass, four of them make the config's 16 spp" if args.config == "c5" else ""),
+                       "step": "one pass of the reference's sample loop over the whole frame; the K steps are ONE rtw_render_passes call, whose passes are rendered in "
+                               "groups that share one set of launches (every pixel's accumulate + ARGB resolve still runs once per pass, in pass order)",
+                       "sharding": "10-row tasks round-robin over ranks, one gather of the rows to rank 0 after the K passes",
+                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "pipeline_run": ctx.last_pass_pipeline()},
+            "camera_Mrays_per_s": cam_total / elapsed / 1e6,
+            "nontrivial_Mrays_per_s": nontrivial / elapsed / 1e6,
+            "nontrivial_rays_note": "rays that meet a shape's culling box: camera rays by pixel-centre direction (%d of %d per pass) + all secondary rays" % (nontrivial_cam, npix * spp),
             "rays_per_frame": rays_total / K,
+            "verified_bit_identical_to_single_kernel_replay": verified,
+            "scene_commit_ms": commit_ms,
+            "bins_and_tables_build_ms": max(0.0, first_call_ms - second_call_ms),
+            "host_setup_note": "scene_commit_ms = tree build (host, the reference's split decisions) + derived layouts + upload; bins_and_tables_build_ms = first render call of "
+                               "this frame shape minus the second (screen bins, busy / sky tile lists, job table: host); neither is in the timed region",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": ("render pass = primary_bins_kernel + per-bounce shade_kernel / trace_wave_kernel rounds + resolve_kernel (one rtw_render_tasks call)" if args.pipeline == 3
-                                    else "render pass = primary_kernel + path kernels + resolve_kernel (one rtw_render_tasks call)" if args.pipeline >= 1 else "render_kernel"),
+                         "frac_algorithmic": achieved / HBM_PEAK_GBS,
+                         "frac_hbm_measured": (traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "frac_algorithmic_reference_order": alg_ref / world / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "limiter": "not bandwidth: the tree, bins and (small meshes) triangle records stay in LDS / L2 / Infinity Cache, measured HBM traffic is a fraction of the "
+                                    "algorithmic bytes; the pass is bound by VALU issue in lock-step ray walks and by the latency of its chain of dependent launches",
+                         "bytes_model": "SURVEY.md 8(d): 32 B/box test + 48 B/triangle test + 64 B/shaded hit + 16 B/texture sample + 36 B/pixel-pass; `achieved` prices the tests the "
+                                        "timed kernels EXECUTE (bins and pruning provably skip visits the reference makes and rejects); frac_algorithmic_reference_order prices the "
+                                        "reference's own un-pruned visit list and can exceed 1 for that reason",
+                         "kernel": "render pass = 1/K of a group: gprimary (+ gsky beside it) + per-bounce gtrace / gshade rounds + gresolve (rtw_group_kernels.h)" if args.pipeline == 4
+                                   else "render pass (one rtw_render_tasks call)",
                          "kernel_ms": pass_ms,
-                         "stage_ms_with_events_between": dict(zip(("primary", "bounce_rounds", "resolve"), kernel_parts)) if kernel_parts else None,
-                         "loop_ms_per_step_hip_events": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "executed_bytes_per_launch": run_bytes,
-                         "counters_per_frame_reference_order": st_ref, "counters_per_frame_as_run": st_run},
+                         "stage_ms": stage_ms,
+                         "algorithmic_bytes_per_pass_executed": alg_run,
+                         "algorithmic_bytes_per_pass_reference_order": alg_ref,
+                         "counters_per_pass_reference_order": st_ref, "counters_per_pass_as_run": st_run_pass},
         }
-        if verified is not None:
+        if world > 1:
+            result["gather_ms"] = gather_ms
+            result["gather"] = gather_kind + ("; ARGB only" if args.argb_only else "; accumulator + ARGB")
             result["gather_verified_bit_identical_to_1gpu"] = verified
         if world == 1 and not args.no_cpu:
             try:
@@ -391,6 +486,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
     fb.close()
     scene.close()
     ctx.close()

@@ -1,25 +1,52 @@
-// progressive.cpp -- the reference's render thread (UpdateBitmapPixels, Src/RayTracerProgram.cpp:270-422) on the GPU:
-// preview pass, N accumulated passes with the reference's progress line, Output_<spp>spp_<date>.png in SavedImages/.
-//   usage: progressive MESH.obj WIDTH HEIGHT PASSES MAXBOUNCE [OUT.argb]
+// progressive.cpp -- the reference's render thread (UpdateBitmapPixels, Src/RayTracerProgram.cpp:270-422) on the GPU: preview pass, N accumulated
+// passes with the reference's progress line (also the window title), Output_<spp>spp_<date>.png in SavedImages/, and the frames presented
+// to a RenderWindow-shaped sink (Src/Linux/RenderWindow_X11.h:11-30) that counts them here.
+//   usage: progressive MESH.obj WIDTH HEIGHT PASSES MAXBOUNCE [OUT.argb [PASSES_PER_UPDATE]]
 // Build: g++ -std=c++11 -Iinclude examples/progressive.cpp -Lraytracerwin_amd -lrtwin -Wl,-rpath,$PWD/raytracerwin_amd
 #include <cstdio>
 #include <cstdlib>
 
 #include "RayTracerWin.hpp"
 
+struct Seen { int frames; int titles; unsigned long long checksum; };
+static void OnFrame(void* user, const Pixel* px, int w, int h)
+{
+    Seen* s = (Seen*)user;
+    s->frames++;
+    unsigned long long sum = 0;
+    for (int i = 0; i < w * h; i++) sum += px[i] & 0xFFFFFFu;
+    s->checksum = sum;
+}
+static void OnTitle(void* user, const char*) { ((Seen*)user)->titles++; }
+
 int main(int argc, char** argv)
 {
-    if (argc < 6) { std::fprintf(stderr, "usage: %s MESH.obj W H PASSES MAXBOUNCE [OUT.argb]\n", argv[0]); return 2; }
+    if (argc < 6) { std::fprintf(stderr, "usage: %s MESH.obj W H PASSES MAXBOUNCE [OUT.argb [PASSES_PER_UPDATE]]\n", argv[0]); return 2; }
     const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), TotalSamplesNum = std::atoi(argv[4]), MaxBounceTimes = std::atoi(argv[5]);
     try {
         RtwDevice Device(0);
         RayTracerScene Scene(Device);
         Scene.AddShape(RMeshShape::Create(argv[1]), MakeUnique<SurfaceMaterial_Diffuse>(RVec3(1.0f, 1.0f, 1.0f)));
         ColorBuffer Buffer(Device, W, H);
-        const std::string Saved = UpdateBitmapPixels(Device, Scene, Buffer, TotalSamplesNum, MaxBounceTimes);
+        // the display hook, as RayTracerProgram::Run sets its window up (Src/RayTracerProgram.cpp:445-455)
+        std::vector<Pixel> Shown((size_t)W * H);
+        Seen seen = { 0, 0, 0ull };
+        RenderWindow Window;
+        Window.Create(W, H);
+        Window.SetRenderBufferParameters(W, H, Shown.data());
+        Window.SetSinks(OnFrame, OnTitle, &seen);
+        RtwProgressive Run;
+        Run.TotalSamplesNum = TotalSamplesNum; Run.MaxBounceTimes = MaxBounceTimes; Run.Window = &Window;
+        Run.PassesPerUpdate = argc > 7 ? std::atoi(argv[7]) : 1;
+        const std::string Saved = UpdateBitmapPixels(Device, Scene, Buffer, Run);
+        Window.RunWindowLoop();
         if (argc > 6) {
             const std::vector<Pixel> bitcolor = Buffer.bitcolor();
             FILE* f = std::fopen(argv[6], "wb"); std::fwrite(bitcolor.data(), 4, bitcolor.size(), f); std::fclose(f);
+            unsigned long long sum = 0;
+            for (size_t i = 0; i < bitcolor.size(); i++) sum += bitcolor[i] & 0xFFFFFFu;
+            std::printf("window: %d frames presented, %d titles, last frame %s the final image; title: %s\n", seen.frames, seen.titles,
+                        sum == seen.checksum ? "equals" : "DIFFERS FROM", Window.GetTitle().c_str());
         }
         std::printf("saved: %s\n", Saved.c_str());
     } catch (const RtwFailure& e) {

@@ -290,64 +290,137 @@ public:
     }
 };
 
-// ---- Src/RayTracerProgram.cpp:270-422 -----------------------------------------------------------------------------------------------
-// UpdateBitmapPixels: the base-colour preview pass, then TotalSamplesNum accumulated passes over the whole frame (the
-// reference's 10-row tasks are one rtw_render_passes call; after the first passes the library replays one launch graph
-// per pass), the reference's progress line per pass, cooperative quit, and the PNG written as
-// Output_<spp>spp_<date>.png into the first of SavedImages/, ../SavedImages/, ../../SavedImages/ that holds Output.txt.
-// Returns the path of the image written ("" if no output folder was found or the run was asked to stop before any pass).
-inline void FormatTimeString(char* Buffer, size_t Size, int TimeMs)          // Src/RayTracerProgram.cpp:242-268
+// ---- Src/Linux/RenderWindow_X11.h:11-30 (and its Windows / OSX twins): the display hook ------------------------------------------------
+// The reference blits bitcolor[] to a native window and writes the progress line into its title.  On a headless GPU node the same
+// four calls feed a SINK: every presented frame (the resolved 0xAARRGGBB image) and every title go to callbacks, if set, and are
+// counted.  SetRenderBufferParameters names the caller's pixel buffer exactly like the reference's call (width, height, buffer);
+// the renderer copies the device image into it before each Present().
+class RenderWindow {
+public:
+    typedef void (*FrameSink)(void* User, const Pixel* Pixels, int Width, int Height);
+    typedef void (*TitleSink)(void* User, const char* Title);
+    RenderWindow() : Width(0), Height(0), Buffer(nullptr), OnFrame(nullptr), OnTitle(nullptr), User(nullptr), Frames(0), Created(false), Closing(false) {}
+    bool Create(int InWidth, int InHeight) { if (InWidth <= 0 || InHeight <= 0) return false; Width = InWidth; Height = InHeight; Created = true; return true; }
+    void SetRenderBufferParameters(int BufferWidth, int BufferHeight, void* InBuffer) { Width = BufferWidth; Height = BufferHeight; Buffer = (Pixel*)InBuffer; }
+    void SetTitle(const char* InTitle) { Title = InTitle ? InTitle : ""; if (OnTitle) OnTitle(User, Title.c_str()); }
+    // the reference's loop pumps native events until the window closes; a sink has no events: it returns once the renderer is done
+    void RunWindowLoop() { Closing = true; }
+    void SetSinks(FrameSink InFrame, TitleSink InTitle, void* InUser) { OnFrame = InFrame; OnTitle = InTitle; User = InUser; }
+    // called by the renderer after the buffer named in SetRenderBufferParameters has been refreshed
+    void Present() { Frames++; if (OnFrame && Buffer) OnFrame(User, Buffer, Width, Height); }
+    Pixel* RenderBuffer() const { return Buffer; }
+    int BufferWidth() const { return Width; }
+    int BufferHeight() const { return Height; }
+    const std::string& GetTitle() const { return Title; }
+    int PresentedFrames() const { return Frames; }
+    bool IsCreated() const { return Created; }
+private:
+    int Width, Height; Pixel* Buffer; FrameSink OnFrame; TitleSink OnTitle; void* User; std::string Title; int Frames; bool Created, Closing;
+};
+
+// ---- Src/RayTracerProgram.cpp:242-268 ----------------------------------------------------------------------------------------------
+// "12ms" below a second, else "3s", "2m:5s", "1h:0m:7s" (minutes and seconds are the remainders, as the reference computes them)
+inline void FormatTimeString(char* Buffer, int BufferSize, int Milliseconds)
 {
-    const int s = TimeMs / 1000, m = s / 60, h = m / 60;
-    if (h > 0) std::snprintf(Buffer, Size, "%dh %dm %ds", h, m % 60, s % 60);
-    else if (m > 0) std::snprintf(Buffer, Size, "%dm %ds", m, s % 60);
-    else std::snprintf(Buffer, Size, "%ds", s);
+    if (Milliseconds < 1000) { std::snprintf(Buffer, (size_t)BufferSize, "%dms", Milliseconds); return; }
+    const int Hours = Milliseconds / 3600000;
+    const int Minutes = Milliseconds / 60000 - Hours * 60;
+    const int Seconds = Milliseconds / 1000 - Minutes * 60 - Hours * 3600;
+    if (Hours != 0) std::snprintf(Buffer, (size_t)BufferSize, "%dh:%dm:%ds", Hours, Minutes, Seconds);
+    else if (Minutes != 0) std::snprintf(Buffer, (size_t)BufferSize, "%dm:%ds", Minutes, Seconds);
+    else std::snprintf(Buffer, (size_t)BufferSize, "%ds", Seconds);
 }
+
+// ---- Src/RayTracerProgram.cpp:270-422: the progressive render -------------------------------------------------------------------
+// What the reference's UpdateBitmapPixels does, on the device: one base-colour preview pass, then TotalSamplesNum accumulated passes of
+// the whole frame, a progress line after every update ("RayTracer - S: [n/N] | T: [elapsed / remaining] | F: [frame ms]", also the
+// window title), cooperative quit, and the image saved as Output_<N>spp_<date>.png in the first of SavedImages/, ../SavedImages/,
+// ../../SavedImages/ that holds an Output.txt.
+struct RtwProgressive {
+    int TotalSamplesNum;        // 500 in the reference
+    int MaxBounceTimes;         // 10 in the reference
+    int PassesPerUpdate;        // passes rendered between two progress lines / presents: 1 = the reference's rhythm; more lets the library
+                                // batch the passes of an update into shared launches (several times faster on small frames)
+    uint32_t Seed;
+    const volatile bool* bQuit; // polled after every update (RayTracerProgram::IsTerminating)
+    RenderWindow* Window;       // display hook, may be null
+    int Rank, World;            // this process renders the 10-row tasks t with t % World == Rank ...
+    rtw_comm* Comm;             // ... and the rows travel to rank 0 over RCCL before every present and before the image is saved (null with World == 1)
+    bool ArgbOnlyGather;        // gather the displayable image only (4 B / pixel)
+    bool Quiet;                 // no progress lines on stdout (the title still gets them)
+    RtwProgressive() : TotalSamplesNum(500), MaxBounceTimes(10), PassesPerUpdate(1), Seed(12345), bQuit(nullptr), Window(nullptr), Rank(0), World(1), Comm(nullptr),
+                       ArgbOnlyGather(false), Quiet(false) {}
+};
+
+// Returns the path of the image written; "" when no output folder was found, nothing was rendered, or this is not rank 0.
+inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, ColorBuffer& Buffer, const RtwProgressive& Run)
+{
+    using Clock = std::chrono::system_clock;
+    const int TaskRows = 10;                       // NumTaskRows
+    const bool Root = Run.Rank == 0;
+    auto Show = [&](const char* Text) {            // gather (several ranks), refresh the window's buffer, present
+        if (Run.World > 1 && Run.Comm) RtwCheck(rtw_gather_rows(Run.Comm, Buffer.Get(), TaskRows, Run.ArgbOnlyGather ? RTW_GATHER_ARGB : RTW_GATHER_ALL));
+        if (!Root || !Run.Window) return;
+        if (Text) Run.Window->SetTitle(Text);
+        if (Run.Window->RenderBuffer() && Run.Window->BufferWidth() == Buffer.bitmapWidth() && Run.Window->BufferHeight() == Buffer.bitmapHeight()) {
+            RtwCheck(rtw_framebuffer_resolve_argb(Buffer.Get(), Run.Window->RenderBuffer()));
+            Run.Window->Present();
+        }
+    };
+    // the preview: every material's base colour, no bounces
+    RtwCheck(rtw_render_tasks(Scene.Get(), Buffer.Get(), TaskRows, Run.Rank, Run.World, Run.MaxBounceTimes, 1, 0, 4, Run.Seed));
+    Show(nullptr);
+    Device.Synchronize();
+    const Clock::time_point Begin = Clock::now();
+    Clock::time_point Previous = Begin;
+    const int Step = Run.PassesPerUpdate > 0 ? Run.PassesPerUpdate : 1;
+    int Rendered = 0;
+    while (Rendered < Run.TotalSamplesNum) {
+        const int Count = Run.TotalSamplesNum - Rendered < Step ? Run.TotalSamplesNum - Rendered : Step;
+        RtwCheck(rtw_render_passes(Scene.Get(), Buffer.Get(), TaskRows, Run.Rank, Run.World, Run.MaxBounceTimes, 0, Rendered, Count, 4, Run.Seed));
+        Rendered += Count;
+        Device.Synchronize();
+        const Clock::time_point Now = Clock::now();
+        const long long SinceBegin = std::chrono::duration_cast<std::chrono::milliseconds>(Now - Begin).count();
+        const long long Left = SinceBegin / Rendered * (Run.TotalSamplesNum - Rendered);           // integer milliseconds, as the reference's duration arithmetic
+        const int SinceUpdate = (int)std::chrono::duration_cast<std::chrono::milliseconds>(Now - Previous).count();
+        Previous = Now;
+        char Spent[64], Remaining[64], Line[256];
+        FormatTimeString(Spent, (int)sizeof Spent, (int)SinceBegin);
+        FormatTimeString(Remaining, (int)sizeof Remaining, (int)Left);
+        std::snprintf(Line, sizeof Line, "RayTracer - S: [%d/%d] | T: [%s / %s] | F: [%dms]", Rendered, Run.TotalSamplesNum, Spent, Remaining, SinceUpdate);
+        if (Root && !Run.Quiet) std::printf("%s\n", Line);
+        Show(Line);
+        if (Run.bQuit && *Run.bQuit) break;
+    }
+    if (Run.World > 1 && Run.Comm && !Run.Window) RtwCheck(rtw_gather_rows(Run.Comm, Buffer.Get(), TaskRows, Run.ArgbOnlyGather ? RTW_GATHER_ARGB : RTW_GATHER_ALL));
+    Device.Synchronize();
+    if (Root && !Run.Quiet) std::printf("Finished rendering image.\n");
+    if (!Root || Rendered == 0) return std::string();
+    // Output_<N>spp_<date>.png beside the marker file Output.txt
+    char Stamp[80];
+    const time_t Raw = time(nullptr);
+    strftime(Stamp, sizeof Stamp, "%Y-%m-%d_%H-%M-%S", localtime(&Raw));
+    std::string Folder;
+    const char* Candidates[3] = { "SavedImages/", "../SavedImages/", "../../SavedImages/" };
+    for (int i = 0; i < 3 && Folder.empty(); i++) {
+        std::FILE* Marker = std::fopen((std::string(Candidates[i]) + "Output.txt").c_str(), "rb");
+        if (Marker) { std::fclose(Marker); Folder = Candidates[i]; }
+    }
+    if (Folder.empty()) { std::printf("Unable to find the output folder SavedImages!\n"); return std::string(); }
+    const std::string Filename = Folder + "Output_" + std::to_string(Run.TotalSamplesNum) + "spp_" + Stamp + ".png";
+    const std::vector<Pixel> Image = Buffer.bitcolor();
+    if (!RTexture::SaveBufferToPNG(Filename, Image.data(), Buffer.bitmapWidth(), Buffer.bitmapHeight())) return std::string();
+    std::printf("Image saved as %s\n", Filename.c_str());
+    return Filename;
+}
+
+// the reference's argument-less call with the sample count and bounce limit it compiles in
 inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, ColorBuffer& Buffer, int TotalSamplesNum = 500, int MaxBounceTimes = 10,
                                       const volatile bool* bQuit = nullptr, uint32_t Seed = 12345, bool LogEveryPass = true)
 {
-    const int NumTaskRows = 10;
-    // Draw base color for preview
-    RtwCheck(rtw_render_tasks(Scene.Get(), Buffer.Get(), NumTaskRows, 0, 1, MaxBounceTimes, 1, 0, 4, Seed));
-    Device.Synchronize();
-    const std::chrono::system_clock::time_point StartTime = std::chrono::system_clock::now();
-    std::chrono::system_clock::time_point LastFrameTime = StartTime;
-    int Done = 0;
-    for (int Sample = 0; Sample < TotalSamplesNum; Sample++) {
-        RtwCheck(rtw_render_passes(Scene.Get(), Buffer.Get(), NumTaskRows, 0, 1, MaxBounceTimes, 0, Sample, 1, 4, Seed));
-        Done = Sample + 1;
-        if (LogEveryPass || Sample + 1 == TotalSamplesNum) {
-            Device.Synchronize();
-            const std::chrono::system_clock::time_point CurrentTime = std::chrono::system_clock::now();
-            const int ElapsedTimeMs = (int)std::chrono::duration_cast<std::chrono::milliseconds>(CurrentTime - StartTime).count();
-            const int RemainingTimeMs = (int)((long long)ElapsedTimeMs / (Sample + 1) * (TotalSamplesNum - Sample - 1));
-            const int FrameTimeMs = (int)std::chrono::duration_cast<std::chrono::milliseconds>(CurrentTime - LastFrameTime).count();
-            char ElapsedTimeStr[64], RemainingTimeStr[64];
-            FormatTimeString(ElapsedTimeStr, sizeof ElapsedTimeStr, ElapsedTimeMs);
-            FormatTimeString(RemainingTimeStr, sizeof RemainingTimeStr, RemainingTimeMs);
-            std::printf("RayTracer - S: [%d/%d] | T: [%s / %s] | F: [%dms]\n", Sample + 1, TotalSamplesNum, ElapsedTimeStr, RemainingTimeStr, FrameTimeMs);
-            LastFrameTime = CurrentTime;
-        }
-        if (bQuit && *bQuit) break;
-    }
-    Device.Synchronize();
-    std::printf("Finished rendering image.\n");
-    if (Done == 0) return std::string();
-    char stamp[80];
-    const time_t rawtime = time(nullptr);
-    strftime(stamp, sizeof stamp, "%Y-%m-%d_%H-%M-%S", localtime(&rawtime));
-    std::string Filename = std::string("Output_") + std::to_string(TotalSamplesNum) + "spp_" + stamp + ".png";
-    std::string OutputPath("SavedImages/");
-    bool bFoundOutputFolder = false;
-    for (int i = 0; i < 3 && !bFoundOutputFolder; i++) {
-        std::FILE* f = std::fopen((OutputPath + "Output.txt").c_str(), "rb");
-        if (f) { std::fclose(f); bFoundOutputFolder = true; }
-        else OutputPath = std::string("../") + OutputPath;
-    }
-    if (!bFoundOutputFolder) { std::printf("Unable to find the output folder SavedImages!\n"); return std::string(); }
-    Filename = OutputPath + Filename;
-    const std::vector<Pixel> bitcolor = Buffer.bitcolor();
-    if (!RTexture::SaveBufferToPNG(Filename, bitcolor.data(), Buffer.bitmapWidth(), Buffer.bitmapHeight())) return std::string();
-    std::printf("Image saved as %s\n", Filename.c_str());
-    return Filename;
+    RtwProgressive Run;
+    Run.TotalSamplesNum = TotalSamplesNum; Run.MaxBounceTimes = MaxBounceTimes; Run.bQuit = bQuit; Run.Seed = Seed;
+    Run.PassesPerUpdate = LogEveryPass ? 1 : (TotalSamplesNum > 0 ? TotalSamplesNum : 1);
+    return UpdateBitmapPixels(Device, Scene, Buffer, Run);
 }

@@ -218,6 +218,26 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                       int max_bounce, int use_base_color, int first_pass, int n_passes,
                       int sub_samples, uint32_t seed);
 
+/* ---- multi-GPU: the one exchange of the path.  Every rank renders its own tasks (rtw_render_tasks / rtw_render_passes with rank, world)
+ * into a full-size framebuffer; rtw_gather_rows then moves every rank's rows to rank 0 over RCCL (xGMI): grouped ncclSend / ncclRecv
+ * straight out of / into the framebuffers' device memory, on the context's stream, no staging copies.  No reference counterpart (the
+ * reference is one process); it completes what UpdateBitmapPixels' WaitForAllTasksDone (Src/RayTracerProgram.cpp:303) is to one process.
+ * librccl is loaded on first use (dlopen: the copy already in the process, e.g. PyTorch's, else librccl.so.1); single-GPU users never load it. ---- */
+typedef struct rtw_comm rtw_comm;
+#define RTW_COMM_ID_BYTES 128
+/* rank 0: a fresh ncclUniqueId, to be handed to every rank by the caller (MPI, torch.distributed, a file ...) */
+int rtw_comm_unique_id(uint8_t id[RTW_COMM_ID_BYTES]);
+/* every rank: ncclCommInitRank on the context's device */
+int rtw_comm_create(rtw_context* ctx, const uint8_t id[RTW_COMM_ID_BYTES], int rank, int world, rtw_comm** out);
+/* or: use a communicator the caller already has (an ncclComm_t); it stays the caller's */
+int rtw_comm_wrap(rtw_context* ctx, void* nccl_comm, int rank, int world, rtw_comm** out);
+int rtw_comm_destroy(rtw_comm* comm);
+#define RTW_GATHER_ALL 0        /* accumulator (16 B / pixel) + ARGB (4 B / pixel) */
+#define RTW_GATHER_ARGB 1       /* the displayable image only, 4 B / pixel */
+/* rows of task t (task_rows rows each, as rtw_render_tasks deals them: t belongs to rank t % world) travel from their owner to rank 0.
+ * Asynchronous on the context's stream; every rank of the communicator must call it. */
+int rtw_gather_rows(rtw_comm* comm, rtw_framebuffer* fb, int task_rows, int mode);
+
 /* work counters of launches since the last reset (only counted while enabled) */
 int rtw_stats_enable(rtw_context* ctx, int enabled);
 int rtw_stats_reset(rtw_context* ctx);

@@ -291,6 +291,7 @@ struct AccPixel { RVec3 sum; int n; };
 // The reference's own pixel-range worker and the buffers it writes (external linkage, Src/RayTracerProgram.cpp:49,77,131).
 // AccumulatePixel is defined in that .cpp only; this declaration has its two data members in the same order (16 bytes).
 void ThreadWorker_Render(int begin, int end, int MaxBounceCount, const RenderOption& InOption);
+void FormatTimeString(char* Buffer, int BufferSize, int Milliseconds);
 extern Pixel bitcolor[];
 struct AccumulatePixel { RVec3 AccumulatedColor; int Num; };
 extern AccumulatePixel accuBuffer[];
@@ -544,8 +545,15 @@ int main(int argc, char** argv)
         return RTexture::SaveBufferToPNG(argv[5], px.data(), w, h) ? 0 : 7;
     }
 
-    // timestring MS... : RayTracerProgram's FormatTimeString through a progress line is not reachable from outside (a static function);
-    // see tests/test_facade_cpp.py for the format pinned from the source text.
+    // timestring MS... : the reference's own FormatTimeString (Src/RayTracerProgram.cpp:242-268, external linkage), one line per argument
+    if (cmd == "timestring" && argc >= 3) {
+        for (int i = 2; i < argc; i++) {
+            char buf[256];
+            FormatTimeString(buf, (int)sizeof buf, atoi(argv[i]));
+            printf("%s %s\n", argv[i], buf);
+        }
+        return 0;
+    }
 
     fprintf(stderr, "ref_harness: bad command line\n");
     return 1;

@@ -9,10 +9,10 @@ interface for that path, over ctypes: same names, same argument meaning
 fallback: without the built library or without a GPU every device call raises.
 """
 from .api import (  # noqa: F401
-    Context, Framebuffer, RayTracerScene, RCapsule, RMeshShape, RPlane, RSphere, RTriangle, RenderOption, RtwError,
+    Comm, Context, Framebuffer, RayTracerScene, RCapsule, RMeshShape, RPlane, RSphere, RTriangle, RenderOption, RtwError,
     SurfaceMaterial_Blend, SurfaceMaterial_Combine, SurfaceMaterial_Diffuse, SurfaceMaterial_DiffuseChecker,
     SurfaceMaterial_Emissive, SurfaceMaterial_Null, SurfaceMaterial_Reflective,
-    ThreadWorker_Render, build_library, library, library_path, material_nodes_from_array,
+    ThreadWorker_Render, build_library, library, library_path, material_nodes_from_array, png_load,
 )
 
 __all__ = [n for n in dir() if not n.startswith("_")]

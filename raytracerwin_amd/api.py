@@ -306,6 +306,37 @@ class Context:
             pass
 
 
+class Comm:
+    """rtw_comm: an RCCL communicator for the one exchange of the path (rtw_gather_rows).  `bootstrap` hands rank 0's 128-byte id to every
+    rank: a callable bytes -> bytes (e.g. a torch.distributed / MPI broadcast); with world == 1 nothing is exchanged."""
+
+    def __init__(self, ctx, rank, world, bootstrap=None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.h = C.c_void_p()
+        ctx._children.add(self)
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _check(library().rtw_comm_unique_id(ident))
+        if self.world > 1:
+            raw = bootstrap(bytes(ident))
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        _check(library().rtw_comm_create(ctx.h, ident, self.rank, self.world, C.byref(self.h)))
+
+    def gather_rows(self, fb, task_rows, argb_only=False):
+        _check(library().rtw_gather_rows(self.h, fb.h, int(task_rows), 1 if argb_only else 0))
+
+    def close(self):
+        if getattr(self, "h", None):
+            library().rtw_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Framebuffer:
     """accuBuffer[] + bitcolor[] (Src/RayTracerProgram.cpp:49-77) on the device."""
 

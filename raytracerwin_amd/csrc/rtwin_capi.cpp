@@ -1132,6 +1132,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     int kshift = 0; while ((1 << kshift) < n_passes) kshift++;
     g.kshift = kshift;
     g.range_begin = range_begin; g.range_end = range_end; g.first_tile = 0;
+    if (cx->stats_enabled) ranged = true;       // work counters: every camera ray goes through the primary kernel, which counts (the sky kernel does not)
     if (ranged) {           // every tile of the range is a job; the primary kernel finds out which see the sky only
         g.n_busy = p.count >> 6; g.n_sky = 0; g.n_jobs = g.n_busy;
         g.busy_tiles = nullptr; g.sky_tiles = nullptr; g.jobs = nullptr;
@@ -1399,7 +1400,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
         {
             RtwRenderParams t = p; t.width = fb->width; t.height = fb->height;
             rtw_scene::BinSet* bs = nullptr; const rtw_scene::GroupTable* gt = nullptr;
-            if (choose_group_tiles(t, 0, fb->width * fb->height - 1) && scene_bins(scene, t.width, t.height, t.tile_w, t.tile_h, &bs) == RTW_OK &&
+            if (!cx->stats_enabled && choose_group_tiles(t, 0, fb->width * fb->height - 1) && scene_bins(scene, t.width, t.height, t.tile_w, t.tile_h, &bs) == RTW_OK &&
                 scene_group_table(scene, *bs, t, sub_samples, &gt) == RTW_OK && gt) per_pass = (long long)gt->n_busy * 64 * sub_samples;
         }
         int done = 0;
@@ -1477,6 +1478,154 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
         g.scene = scene; g.fb = fb; g.task_rows = task_rows; g.rank = rank; g.world = world; g.max_bounce = max_bounce;
         g.preview = use_base_color ? 1 : 0; g.sub_samples = sub_samples; g.seed = seed; g.next_pass = pass + 1;
     }
+    return RTW_OK;
+}
+
+// ---- multi-GPU gather over RCCL -------------------------------------------------------------------------------------------------
+}  // extern "C"
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is loaded with dlopen on first use
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+const RcclApi* rccl_api()
+{
+    std::lock_guard<std::mutex> l(g_rccl_mutex);
+    if (g_rccl.handle) return &g_rccl;
+    // the copy the process already holds (PyTorch ships its own librccl.so), else the ROCm one
+    const char* names[] = { "librccl.so.1", "librccl.so" };
+    void* h = nullptr;
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g_rccl.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+    RcclApi a; a.handle = h;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+    a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv) {
+        g_rccl.error = "librccl lacks a needed symbol"; return nullptr;
+    }
+    g_rccl = a;
+    return &g_rccl;
+}
+int rccl_fail(const RcclApi* a, ncclResult_t r, const char* what)
+{
+    return fail(RTW_ERR_HIP, std::string(what) + ": " + ((a && a->GetErrorString) ? a->GetErrorString(r) : "rccl error"));
+}
+}  // namespace
+
+struct rtw_comm {
+    rtw_context* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owned = false;
+    int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int rtw_comm_unique_id(uint8_t id[RTW_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == RTW_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id) return fail(RTW_ERR_INVALID, "null argument");
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(RTW_ERR_STATE, g_rccl.error);
+    ncclUniqueId u;
+    const ncclResult_t r = a->GetUniqueId(&u);
+    if (r != ncclSuccess) return rccl_fail(a, r, "ncclGetUniqueId");
+    std::memcpy(id, &u, RTW_COMM_ID_BYTES);
+    return RTW_OK;
+}
+
+int rtw_comm_create(rtw_context* ctx, const uint8_t id[RTW_COMM_ID_BYTES], int rank, int world, rtw_comm** out)
+{
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return fail(RTW_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(RTW_ERR_STATE, g_rccl.error);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u; std::memcpy(&u, id, RTW_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = a->CommInitRank(&c, world, u, rank);
+    if (r != ncclSuccess) return rccl_fail(a, r, "ncclCommInitRank");
+    rtw_comm* k = new rtw_comm(); k->ctx = ctx; k->comm = c; k->owned = true; k->rank = rank; k->world = world;
+    *out = k;
+    return RTW_OK;
+}
+
+int rtw_comm_wrap(rtw_context* ctx, void* nccl_comm, int rank, int world, rtw_comm** out)
+{
+    if (!ctx || !nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return fail(RTW_ERR_INVALID, "bad argument");
+    if (!rccl_api()) return fail(RTW_ERR_STATE, g_rccl.error);
+    rtw_comm* k = new rtw_comm(); k->ctx = ctx; k->comm = (ncclComm_t)nccl_comm; k->owned = false; k->rank = rank; k->world = world;
+    *out = k;
+    return RTW_OK;
+}
+
+int rtw_comm_destroy(rtw_comm* comm)
+{
+    if (!comm) return RTW_OK;
+    if (comm->owned && comm->comm) {
+        (void)hipSetDevice(comm->ctx->device);
+        (void)hipStreamSynchronize(comm->ctx->stream);
+        const RcclApi* a = rccl_api();
+        if (a) (void)a->CommDestroy(comm->comm);
+    }
+    delete comm;
+    return RTW_OK;
+}
+
+int rtw_gather_rows(rtw_comm* comm, rtw_framebuffer* fb, int task_rows, int mode)
+{
+    if (!comm || !fb) return fail(RTW_ERR_INVALID, "null argument");
+    if (fb->ctx != comm->ctx) return fail(RTW_ERR_INVALID, "communicator and framebuffer belong to different contexts");
+    if (task_rows < 1 || (mode != RTW_GATHER_ALL && mode != RTW_GATHER_ARGB)) return fail(RTW_ERR_INVALID, "bad argument");
+    if (comm->world == 1) return RTW_OK;
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(RTW_ERR_STATE, g_rccl.error);
+    HIP_TRY(hipSetDevice(comm->ctx->device));
+    hipStream_t st = comm->ctx->stream;
+    const int W = fb->width, H = fb->height;
+    const int n_tasks = (H + task_rows - 1) / task_rows;
+    ncclResult_t r = ncclSuccess;
+    // a task's rows are contiguous in both buffers; ranks and root walk the tasks in the same order, so the point-to-point operations of a
+    // pair match up in issue order.  Groups of 64 tasks keep the number of operations per group moderate.
+    for (int t0 = 0; t0 < n_tasks && r == ncclSuccess; t0 += 64) {
+        if ((r = a->GroupStart()) != ncclSuccess) break;
+        for (int t = t0; t < n_tasks && t < t0 + 64 && r == ncclSuccess; t++) {
+            const int owner = t % comm->world;
+            if (owner == 0 || (comm->rank != 0 && comm->rank != owner)) continue;
+            const int rows = std::min(task_rows, H - t * task_rows);
+            const size_t off = (size_t)t * (size_t)task_rows * (size_t)W, cnt = (size_t)rows * (size_t)W;
+            if (comm->rank == 0) {
+                if (mode == RTW_GATHER_ALL) r = a->Recv((char*)fb->accum + off * 16, cnt * 16, ncclChar, owner, comm->comm, st);
+                if (r == ncclSuccess) r = a->Recv((char*)fb->argb + off * 4, cnt * 4, ncclChar, owner, comm->comm, st);
+            } else {
+                if (mode == RTW_GATHER_ALL) r = a->Send((const char*)fb->accum + off * 16, cnt * 16, ncclChar, 0, comm->comm, st);
+                if (r == ncclSuccess) r = a->Send((const char*)fb->argb + off * 4, cnt * 4, ncclChar, 0, comm->comm, st);
+            }
+        }
+        const ncclResult_t e = a->GroupEnd();
+        if (r == ncclSuccess) r = e;
+    }
+    if (r != ncclSuccess) return rccl_fail(a, r, "rtw_gather_rows");
     return RTW_OK;
 }
 

@@ -146,6 +146,24 @@ def golden_worker(tag, name, mat, depth, preview, seed, pass0, npass, tmp):
                         band=np.array([368, 432], np.int64), accum_band=accum[band])
 
 
+def golden_misc(tmp):
+    """Small facts straight from the reference's own functions: FormatTimeString's renderings (Src/RayTracerProgram.cpp:242-268) and a PNG
+    written by RTexture::SaveBufferToPNG (Src/Texture.cpp:201-283) with its decoded pixels."""
+    import json
+    from PIL import Image
+    ms = [0, 1, 999, 1000, 1001, 59999, 60000, 61000, 125000, 3599999, 3600000, 3661000, 3725000, 86400000 + 62000]
+    out = subprocess.check_output([H, "timestring"] + [str(v) for v in ms]).decode().strip().splitlines()
+    table = {int(ln.split(" ", 1)[0]): ln.split(" ", 1)[1] for ln in out}
+    json.dump(table, open(os.path.join(OUT, "timestrings.json"), "w"), indent=0, sort_keys=True)
+    g = np.load(os.path.join(OUT, "frame_unitychan_diffuse_d4.npz"))
+    W, Hh = int(g["params"][0]), int(g["params"][1])
+    argb = g["argb"].astype(np.uint32)
+    ap, pp = os.path.join(tmp, "img.argb"), os.path.join(OUT, "png_written_by_reference.png")
+    argb.tofile(ap)
+    run(["savepng", ap, W, Hh, pp])
+    np.savez_compressed(os.path.join(OUT, "png_reference_decode.npz"), argb=argb, size=np.array([W, Hh]), rgb=np.asarray(Image.open(pp).convert("RGB")))
+
+
 def main_worker(tmp):
     golden_worker("torus_mirror_d4", "TorusKnot", "mirror", 4, 0, 31, 0, 2, tmp)
     golden_worker("unitychan_preview", "unitychan", "diffuse", 4, 1, 31, 0, 1, tmp)
@@ -238,6 +256,10 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             main_worker(tmp)
         return
+    if "--misc-only" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            golden_misc(tmp)
+        return
     if "--scenes-only" in sys.argv:        # add the multi-shape fixtures without regenerating the others
         rng = np.random.default_rng(20261005)
         with tempfile.TemporaryDirectory() as tmp:
@@ -270,6 +292,7 @@ def main():
         golden_raytrace("monkey_blendfuzz", "BlenderMonkey", "blendfuzz", 900, 6, 4242, 1920, 1080, tmp, rng, bounds["BlenderMonkey"])
         main_scenes(tmp, np.random.default_rng(20261005), bounds)
         main_worker(tmp)
+        golden_misc(tmp)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("golden fixtures written: %.2f MB" % (total / 1e6))
 

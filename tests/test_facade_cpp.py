@@ -59,6 +59,39 @@ def test_progressive_example_compiles_and_refuses_to_run_without_a_gpu(tmp_path)
     assert r.returncode == 1 and "no HIP device" in r.stderr
 
 
+def test_format_time_string_equals_the_references_own(tmp_path):
+    """tests/golden/timestrings.json holds what the reference's OWN FormatTimeString printed (harness command `timestring`)."""
+    import json
+    from conftest import GOLDEN
+    table = json.load(open(os.path.join(GOLDEN, "timestrings.json")))
+    exe = build_example(tmp_path, "format_time")
+    out = subprocess.check_output([exe] + list(table.keys())).decode().strip().splitlines()
+    got = {ln.split(" ", 1)[0]: ln.split(" ", 1)[1] for ln in out}
+    assert got == table
+
+
+def test_png_writer_decodes_to_what_the_references_writer_decodes_to(tmp_path):
+    """png_reference_decode.npz: an ARGB buffer, and the RGB pixels decoded from the PNG the reference's own RTexture::SaveBufferToPNG
+    (Src/Texture.cpp:201-283) wrote for it; rtw_png_save_argb's file must decode to the same pixels, all three channels, and both files
+    are 8-bit RGB without alpha."""
+    import raytracerwin_amd as R
+    from conftest import GOLDEN
+    from PIL import Image
+    g = np.load(os.path.join(GOLDEN, "png_reference_decode.npz"))
+    W, H = [int(v) for v in g["size"]]
+    argb = np.ascontiguousarray(g["argb"], np.uint32)
+    out = str(tmp_path / "mine.png")
+    import ctypes as C
+    assert R.library().rtw_png_save_argb(out.encode(), argb.ctypes.data_as(C.c_void_p), W, H) == 0
+    mine, ref = Image.open(out), Image.open(os.path.join(GOLDEN, "png_written_by_reference.png"))
+    assert mine.mode == ref.mode == "RGB" and mine.size == ref.size == (W, H)
+    assert (np.asarray(mine) == g["rgb"]).all()
+    assert (np.asarray(ref) == g["rgb"]).all()
+    # and the library's reader reads the reference's file back to the same pixels
+    px = R.png_load(os.path.join(GOLDEN, "png_written_by_reference.png"))
+    assert px.shape == (H, W, 3) and (px == g["rgb"]).all()
+
+
 @pytest.mark.gpu
 def test_update_bitmap_pixels_loop_names_its_png_and_accumulates_like_pass_by_pass_calls(tmp_path):
     """UpdateBitmapPixels of the facade (Src/RayTracerProgram.cpp:270-422): preview pass, N accumulated 4-sub-sample passes,
@@ -70,24 +103,35 @@ def test_update_bitmap_pixels_loop_names_its_png_and_accumulates_like_pass_by_pa
     (tmp_path / "SavedImages" / "Output.txt").write_text("")
     run_dir = tmp_path / "Build"
     run_dir.mkdir()
+    from oracle import oracle as O
     W, H, N = 160, 90, 6
-    raw = str(tmp_path / "o.argb")
-    out = subprocess.run([exe, asset("TorusKnot.obj"), str(W), str(H), str(N), "4", raw], capture_output=True, text=True, cwd=str(run_dir), check=True).stdout
-    assert len(re.findall(r"RayTracer - S: \[\d+/%d\] \| T: \[.* / .*\] \| F: \[\d+ms\]" % N, out)) == N
-    pngs = [f for f in os.listdir(str(tmp_path / "SavedImages")) if re.fullmatch(r"Output_%dspp_\d{4}-\d\d-\d\d_\d\d-\d\d-\d\d\.png" % N, f)]
-    assert len(pngs) == 1
-    cpp = np.fromfile(raw, np.uint32)
-    ctx = R.Context(0)
-    s = R.RayTracerScene(ctx)
-    s.AddShape(R.RMeshShape.Create(asset("TorusKnot.obj")), R.SurfaceMaterial_Diffuse((1, 1, 1)))
-    fb = R.Framebuffer(ctx, W, H)
+    # the ORACLE's image of the same run (CPU restatement of the reference, pinned by the reference's own outputs)
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("TorusKnot.obj"))
+    os_.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+    ofb = O.Framebuffer(W, H)
     for p in range(N):
-        R.ThreadWorker_Render(s, fb, 0, W * H - 1, 4, None, p, 4, 12345)
-    assert (fb.resolve_argb() == cpp).all()
-    from PIL import Image
-    im = np.asarray(Image.open(os.path.join(str(tmp_path / "SavedImages"), pngs[0])))
-    assert im.shape == (H, W, 3) and (im[..., 2].ravel() == cpp & 255).all()
-    ctx.close()
+        os_.render_pass_pool(ofb, 4, False, p, 4, 12345, threads=0, task_rows=10)
+    want = ofb.read()[1]
+    time_re = r"(\d+ms|\d+s|\d+m:\d+s|\d+h:\d+m:\d+s)"
+    for per_update in (1, 4):       # the reference's rhythm (a line per pass), and passes batched four to an update
+        for f in os.listdir(str(tmp_path / "SavedImages")):
+            if f.endswith(".png"):
+                os.remove(os.path.join(str(tmp_path / "SavedImages"), f))
+        raw = str(tmp_path / ("o%d.argb" % per_update))
+        out = subprocess.run([exe, asset("TorusKnot.obj"), str(W), str(H), str(N), "4", raw, str(per_update)], capture_output=True, text=True, cwd=str(run_dir), check=True).stdout
+        lines = re.findall(r"^RayTracer - S: \[(\d+)/%d\] \| T: \[%s / %s\] \| F: \[\d+ms\]$" % (N, time_re, time_re), out, re.M)
+        assert [int(ln[0]) for ln in lines] == list(range(per_update, N, per_update)) + [N]
+        shown = re.search(r"window: (\d+) frames presented, (\d+) titles, last frame equals the final image; title: RayTracer - S: \[%d/%d\]" % (N, N), out)
+        assert shown and int(shown.group(1)) == len(lines) + 1 and int(shown.group(2)) == len(lines)      # + the preview
+        pngs = [f for f in os.listdir(str(tmp_path / "SavedImages")) if re.fullmatch(r"Output_%dspp_\d{4}-\d\d-\d\d_\d\d-\d\d-\d\d\.png" % N, f)]
+        assert len(pngs) == 1
+        cpp = np.fromfile(raw, np.uint32)
+        assert (cpp == want).all()
+        from PIL import Image
+        im = np.asarray(Image.open(os.path.join(str(tmp_path / "SavedImages"), pngs[0])))
+        assert im.shape == (H, W, 3)
+        assert (im[..., 0].ravel() == (cpp >> 16) & 255).all() and (im[..., 1].ravel() == (cpp >> 8) & 255).all() and (im[..., 2].ravel() == cpp & 255).all()
 
 
 def test_default_scene_example_compiles_and_refuses_to_run_without_a_gpu(tmp_path):
