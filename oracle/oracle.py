@@ -220,9 +220,18 @@ class Scene:
                             C.c_uint32(seed), width, height, _p(out))
         return out
 
-    def render_range(self, fb, begin, end, max_bounce, use_base_color=False, pass_index=0, ns=4, seed=12345):
-        r = lib().orc_render_range(self.h, fb.h, begin, end, max_bounce, int(use_base_color), pass_index, ns,
-                                   C.c_uint32(seed))
+    def render_range(self, fb, begin, end, max_bounce, use_base_color=False, pass_index=0, ns=4, seed=12345, history=None):
+        """history: an optional uint32 array (one word per pixel of the frame) into which the hit / miss history of every rendered
+        pixel's paths is folded (test instrumentation: equal words = the paths took the same branches)"""
+        if history is not None:
+            assert history.dtype == np.uint32 and history.flags["C_CONTIGUOUS"]
+            lib().orc_set_history_buffer(_p(history))
+        try:
+            r = lib().orc_render_range(self.h, fb.h, begin, end, max_bounce, int(use_base_color), pass_index, ns,
+                                       C.c_uint32(seed))
+        finally:
+            if history is not None:
+                lib().orc_set_history_buffer(None)
         if r != 0:
             raise RuntimeError("oracle: render_range bad arguments")
 

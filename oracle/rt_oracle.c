@@ -929,13 +929,25 @@ static vec3 material_preview(const eval_ctx* cx, const material_t* mt, int node,
     }
 }
 
+/* Test instrumentation: a per-pixel signature of the hit / miss HISTORY of the pixel's paths -- every scene query folds (bounce level, shape hit
+ * or -1, triangle) into the word of the pixel being rendered.  Two renders whose signatures agree in a pixel took the same branches there. */
+static uint32_t* g_history = NULL;
+static __thread uint32_t* t_history_word = NULL;
+void orc_set_history_buffer(uint32_t* buf) { g_history = buf; }
+static inline void history_note(int level, int shape, int tri)
+{
+    if (t_history_word) *t_history_word = mix32(*t_history_word ^ (uint32_t)(level * 0x9E3779B1u) ^ ((uint32_t)(shape + 1) << 24) ^ (uint32_t)(tri + 1));
+}
+
 /* RayTracerScene::RayTrace (Src/RayTracerScene.cpp:31-97) */
 static vec3 ray_trace(const orc_scene* sc, const ray_t* in_ray, int max_bounce, int use_base_color, path_rng* rng, uint32_t phase)
 {
     if (max_bounce == 0) return v3(0, 0, 0);
     vec3 final_color = v3(0, 0, 0);
     hit_t result; hit_init(&result);
-    int hit_shape = find_intersection(sc, *in_ray, &result, NULL);
+    int hit_tri = -1;
+    int hit_shape = find_intersection(sc, *in_ray, &result, t_history_word ? &hit_tri : NULL);
+    history_note(max_bounce, hit_shape, hit_shape != -1 ? hit_tri : -1);
     if (hit_shape != -1) {
         const shape_t* s = &sc->shapes[hit_shape];
         eval_ctx cx = { sc, rng, phase };
@@ -1071,6 +1083,7 @@ int orc_render_range(const orc_scene* sc, orc_framebuffer* fb, int begin, int en
     const uint32_t phase = table_phase(seed);
     for (int p = begin; p <= end; p++) {
         vec3 c = v3(0, 0, 0);
+        t_history_word = g_history ? &g_history[p] : NULL;
         for (int i = 0; i < ns; i++) {
             path_rng rng; path_rng_init(&rng, seed, npix, p, pass_index, i);
             ray_t ray = camera_ray(w, h, p, i, &rng);

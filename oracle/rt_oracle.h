@@ -121,6 +121,9 @@ void orc_texel_lut(float out256[256]);
 int orc_hw_threads(void);
 void orc_make_pixel_colors(const float* rgb, int64_t n, uint32_t* out);
 
+/* test instrumentation: while set, every pixel rendered folds the hit / miss history of its paths into buf[pixel] (npix words, caller-owned) */
+void orc_set_history_buffer(uint32_t* buf);
+
 #ifdef __cplusplus
 }
 #endif

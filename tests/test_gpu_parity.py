@@ -117,10 +117,14 @@ def test_frame_vs_reference_golden(ctx, tag):
     s = gpu_scene(ctx, str(g["mesh"]), R.material_nodes_from_array(g["material"]))
     accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
     if tag in FUZZY:
-        # fuzzy reflection: the device evaluates sin/cos/acos in double (not libm's float routines), so a
-        # direction may differ in its last bit; tolerance 1e-4 per channel on >= 99.5 % of the pixels
+        # fuzzy reflection: the device evaluates sin/cos/acos in double (not libm's float routines), so a direction may differ in its
+        # last bit.  Stated tolerance: 1e-4 per channel.  OBSERVED on these fixtures (and asserted): every pixel within 2e-6, a handful
+        # differ at all; a deviation beyond 1e-4 could only come from a hit turned into a miss (tests/test_oracle_golden.py::
+        # test_fuzzy_reflection_modes_differ_only_where_the_hit_history_differs shows that with per-pixel hit histories), none occurs here
         d = np.abs(accum[:, :3] - g["accum"][:, :3]).max(axis=1)
-        assert (d <= 1e-4).mean() >= 0.995
+        print("fuzzy frame %s vs the reference: %d of %d pixels differ, max deviation %.3g" % (tag, int((d > 0).sum()), len(d), d.max()))
+        assert d.max() <= 2e-6
+        assert (d > 0).mean() <= 0.01
         assert (accum[:, 3] == g["accum"][:, 3]).all()
         return
     assert (argb == g["argb"]).all()
@@ -156,8 +160,9 @@ def test_ray_trace_vs_reference_golden(ctx, tag):
     s = gpu_scene(ctx, str(g["mesh"]), R.material_nodes_from_array(g["material"]))
     rgb = s.RayTrace(g["rays"], g["keys"], depth, None, seed, W, H)
     if tag == "monkey_blendfuzz":
-        d = np.abs(rgb - g["rgb"]).max(axis=1)       # tolerance 1e-4 (double vs libm transcendentals)
-        assert (d <= 1e-4).mean() >= 0.995
+        d = np.abs(rgb - g["rgb"]).max(axis=1)       # tolerance 1e-4 (double vs libm transcendentals); observed and asserted: 2e-6
+        print("fuzzy rays vs the reference: %d of %d differ, max deviation %.3g" % (int((d > 0).sum()), len(d), d.max()))
+        assert d.max() <= 2e-6
     else:
         assert (bits(rgb) == bits(g["rgb"])).all()
 
@@ -512,7 +517,8 @@ def test_default_scene_with_fuzz_vs_oracle_f64_mode_and_close_to_reference(ctx, 
     accum, argb = render_frame(ctx, s, W, H, ns, depth, preview, seed, pass0, npass)
     assert (bits(accum) == bits(oa)).all() and (argb == ob).all()
     d = np.abs(accum[:, :3] - g["accum"][:, :3]).max(axis=1)
-    assert (d <= 1e-4).mean() >= 0.99
+    print("SetupScene with fuzz vs the reference: %d of %d pixels differ, max deviation %.3g" % (int((d > 0).sum()), len(d), d.max()))
+    assert d.max() <= 2e-6          # stated tolerance 1e-4; observed: 35 of 6 400 pixels differ, by at most 5e-7
 
 
 @pytest.mark.gpu
@@ -726,3 +732,34 @@ def test_frame_vs_the_references_own_thread_worker_render(ctx, tag):
             r0, r1 = [int(v) for v in g["band"]]
             assert (bits(accum[r0 * W:r1 * W]) == bits(g["accum_band"])).all()
             assert worker_digest(accum) == str(g["accum_sha256"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,mesh,W,H,ns,depth,passes,blend", [("c2", "TorusKnot", 1920, 1080, 1, 4, 3, False), ("c3", "BlenderMonkey", 1920, 1080, 4, 6, 2, True),
+                                                                ("c4", "unitychan", 1920, 1080, 4, 4, 2, False), ("c5", "unitychan", 3840, 2160, 4, 8, 4, False)])
+def test_full_size_frames_bit_exact_vs_oracle(ctx, oracle_mod, cfg, mesh, W, H, ns, depth, passes, blend):
+    """BASELINE configs[1..4] at their FULL frame sizes, every pass (C5: all four 4-spp passes of its 16 spp at 3840x2160, depth 8), the GPU's
+    accumulator and ARGB image against the oracle's (its 10-row task pool on the box's host threads), bit for bit, every pixel.
+    C3's material has a fuzzy Reflective: the oracle runs in the device's transcendental mode (see the fuzzy tests for the distance to libm)."""
+    O = oracle_mod
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset(mesh + ".obj"))
+    if blend:
+        os_.set_material(sh, [(O.MAT_BLEND, (0, 0, 0), 0.5, 1, 2), (O.MAT_REFLECTIVE, (1, 1, 1), 0.2, 0, 0), (O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+        os_.set_unitvec_mode(O.UNITVEC_F64)
+        mat = R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((1, 1, 1), 0.2), R.SurfaceMaterial_Diffuse((1, 1, 1)), 0.5)
+    else:
+        os_.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+        mat = R.SurfaceMaterial_Diffuse((1, 1, 1))
+    ofb = O.Framebuffer(W, H)
+    for p in range(passes):
+        os_.render_pass_pool(ofb, depth, False, p, ns, 12345, threads=0, task_rows=10)
+    oa, ob = ofb.read()
+    s = gpu_scene(ctx, mesh, mat)
+    fb = R.Framebuffer(ctx, W, H)
+    s.render_passes(fb, 10, 0, 1, depth, None, 0, passes, ns, 12345)
+    assert ctx.last_pass_pipeline() == DEFAULT_PIPELINE
+    accum, argb = fb.read_float(), fb.resolve_argb()
+    fb.close()
+    assert (argb == ob).all()
+    assert (bits(accum) == bits(oa)).all()
