@@ -408,10 +408,10 @@ def main():
                 if i > 0:
                     acc.append(ctx.last_pass_kernel_ms())
             ctx.set_option("kernel_timing", 0)
-            g = float(min(K, 64))
+            g = float(max(1, ctx.last_group_passes()))
             stage_ms = {"passes_in_the_timed_group": int(g), "primary_per_pass": float(np.mean([k[0] for k in acc])) / g,
                         "bounce_rounds_per_pass": float(np.mean([k[1] for k in acc])) / g, "resolve_per_pass": float(np.mean([k[2] for k in acc])) / g,
-                        "note": "events between the stages of the LAST group of a call; a call of K passes is rendered in groups of at most 64 passes"}
+                        "note": "HIP events between the stages of the LAST group of an untimed call (a call's passes are rendered in groups; the group's size follows the paths per pass)"}
         fb2.close()
 
         rays_total = st["rays"]

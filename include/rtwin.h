@@ -104,6 +104,8 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value);
 /* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's three stages -- primary kernel(s),
  * the per-bounce trace / shade launches, resolve -- measured on the context's stream; waits for that pass. */
 int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3]);
+/* passes the latest group of the pass-batched pipeline held (rtw_last_pass_kernel_ms times that group) */
+int rtw_last_group_passes(rtw_context* ctx);
 /* the pipeline the latest render call of this context actually ran (0..4; -1 before the first call): lets a caller see a fallback */
 int rtw_last_pass_pipeline(rtw_context* ctx);
 const char* rtw_last_error(void);

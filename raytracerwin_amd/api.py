@@ -277,6 +277,9 @@ class Context:
         _check(library().rtw_last_pass_kernel_ms(self.h, out))
         return [float(v) for v in out]
 
+    def last_group_passes(self):
+        return int(library().rtw_last_group_passes(self.h))
+
     def last_pass_pipeline(self):
         """the pipeline the latest render call actually ran (a fallback shows here)"""
         return int(library().rtw_last_pass_pipeline(self.h))

@@ -132,6 +132,8 @@ struct rtw_context {
     struct GroupKey { const void* scene = nullptr; long long capacity = -1; int max_bounce = -1, preview = -1, n_passes = -1;
                       bool operator==(const GroupKey& o) const { return scene == o.scene && capacity == o.capacity && max_bounce == o.max_bounce && preview == o.preview && n_passes == o.n_passes; } };
     GroupKey gcounters_key, known_gkey;
+    int gcounters_passes = 1;           // passes of the group whose lengths are in flight
+    int last_group_passes = 0;          // passes of the latest group (rtw_last_group_passes)
     int known_ground[32];
     int known_goverflow[24];
     int visit_budget = 256;             // one-mesh scenes with a big tree: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
@@ -357,6 +359,12 @@ int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3])
     HIP_TRY(hipEventSynchronize(ctx->timing_events[3]));
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out3[i], ctx->timing_events[i], ctx->timing_events[i + 1]));
     return RTW_OK;
+}
+
+int rtw_last_group_passes(rtw_context* ctx)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    return ctx->last_group_passes;
 }
 
 int rtw_last_pass_pipeline(rtw_context* ctx)
@@ -1146,7 +1154,14 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     const bool carry = scene->texture_carry;
     const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
     if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");
-    rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
+    {   // room for the largest group the grouping policy can form for this launch shape, so that a later, longer call does not reallocate
+        // (a reallocation waits for the stream: measured 0.3 ms inside a timed 20-pass call that followed a 5-pass warm-up)
+        const long long per_pass = (long long)g.n_busy * 64 * sub_samples;
+        const int kmax = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, INT32_MAX, max_bounce, carry);
+        int ks = 0; while ((1 << ks) < kmax) ks++;
+        if (ks < kshift) ks = kshift;
+        rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(((size_t)g.n_busy * 64 * (size_t)sub_samples) << ks, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
+    }
     rtw::GroupTuning tune;
     tune.capacity = capacity;
     tune.aux_stream = cx->sky_split ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
@@ -1167,24 +1182,29 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 3 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
     tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
-    rtw_context::GroupKey key; key.scene = scene; key.capacity = (long long)capacity; key.max_bounce = max_bounce; key.preview = p.preview; key.n_passes = n_passes;
+    // (keyed by the launch shape WITHOUT the number of passes: the lengths are kept per pass and scaled to the group at hand, so a warm-up call of any
+    // length primes a longer one)
+    rtw_context::GroupKey key; key.scene = scene; key.capacity = (long long)((size_t)g.n_busy * 64 * (size_t)sub_samples); key.max_bounce = max_bounce; key.preview = p.preview; key.n_passes = 0;
     if (cx->gcounters_pending && hipEventQuery(cx->gcounters_event) == hipSuccess) {
         cx->known_gkey = cx->gcounters_key; cx->gcounters_pending = false;
-        for (int r = 0; r < 32; r++) cx->known_ground[r] = (int)cx->h_gcounters[r];
-        for (int r = 0; r < 24; r++) cx->known_goverflow[r] = (int)cx->h_gcounters[40 + r];
+        const int np = cx->gcounters_passes > 0 ? cx->gcounters_passes : 1;
+        for (int r = 0; r < 32; r++) cx->known_ground[r] = (int)((cx->h_gcounters[r] + (uint32_t)np - 1u) / (uint32_t)np);          // per pass, rounded up
+        for (int r = 0; r < 24; r++) cx->known_goverflow[r] = (int)((cx->h_gcounters[40 + r] + (uint32_t)np - 1u) / (uint32_t)np);
     }
-    for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_gkey == key) ? cx->known_ground[r] : -1;
-    for (int r = 0; r < 24; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? cx->known_goverflow[r] : -1;
+    auto scaled = [&](int per_pass) { const long long v = (long long)per_pass * n_passes; return (int)(v > INT32_MAX ? INT32_MAX : v); };
+    for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_ground[r]) : -1;
+    for (int r = 0; r < 24; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_goverflow[r]) : -1;
     for (int r = 24; r < 32; r++) tune.overflow_hint[r] = -1;
     cx->group_clean = false;
     const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws, g, tune, cx->stats_enabled, cx->stream);
     if (e != hipSuccess) return hip_fail(e, "group launch");
     cx->group_clean = true;
     cx->last_pipeline = 4;
+    cx->last_group_passes = n_passes;
     if (!cx->gcounters_pending && g.n_busy > 0 && (!(cx->known_gkey == key) || (cx->hint_tick++ % cx->hint_period) == 0)) {
         if (hipMemcpyAsync(cx->h_gcounters, (char*)cx->d_group_ws + 256, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
             hipEventRecord(cx->gcounters_event, cx->stream) == hipSuccess) {
-            cx->gcounters_pending = true; cx->gcounters_key = key;
+            cx->gcounters_pending = true; cx->gcounters_key = key; cx->gcounters_passes = n_passes;
         }
     }
     return RTW_OK;
