@@ -2357,7 +2357,9 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
 #undef RTW_LAUNCH_GP
                     if (tune.visit_budget < INT32_MAX) {        // the rays that ran out of budget: a wave each
                         constexpr int NTV = 128;
-                        long long want = tune.overflow_hint[r - 1] >= 0 ? (long long)tune.overflow_hint[r - 1] * 2 + 256 : 16384;
+                        // a generous grid: the count varies from group to group, a wave-per-ray loop with too few waves is slow (measured: 0.9 ms for a few
+                        // thousand rays on 256 waves), blocks without a ray leave at once
+                        long long want = tune.overflow_hint[r - 1] >= 0 ? (long long)tune.overflow_hint[r - 1] * 4 + 8192 : 16384;
                         long long blocks = (want + NTV / 64 - 1) / (NTV / 64);
                         const long long cap = (long long)tune.cu_count * 64;
                         if (blocks > cap) blocks = cap;

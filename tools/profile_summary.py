@@ -46,14 +46,14 @@ def timed_dispatch_window(trace_csv, steps):
 
 
 def window_of_timed_call(names, k_steps, warm):
-    """indices [a, b) of the timed call's dispatches.  Calls before it: (1 pass), (1 pass), (warm passes) -> each ends with a gresolve per group; groups hold at most 64 passes."""
-    groups_before = 1 + 1 + ((warm + 63) // 64 if warm > 0 else 0)
-    timed_groups = (k_steps + 63) // 64
-    res = [i for i, n in enumerate(names) if n == "gresolve_kernel"]
-    if len(res) < groups_before + timed_groups:
-        return 0, len(names)
-    a = res[groups_before - 1] + 1
-    b = res[groups_before + timed_groups - 1] + 1
+    """indices [a, b) of the timed call's dispatches: bench.py zeroes the two framebuffer tensors (two torch fill kernels) right before the timed
+    rtw_render_passes call and replays the passes through render_kernel (pipeline 0) right after it; everything between is the timed call."""
+    replay = [i for i, n in enumerate(names) if n == "render_kernel"]
+    b = replay[0] if replay else len(names)
+    fills = [i for i, n in enumerate(names[:b]) if "elementwise" in n]
+    a = fills[-1] + 1 if fills else 0
+    while b > a and not (names[b - 1].startswith("g") or "primary" in names[b - 1] or "shade" in names[b - 1] or "trace" in names[b - 1] or "resolve" in names[b - 1]):
+        b -= 1
     return a, b
 
 
