@@ -1,0 +1,231 @@
+// rtw_build_kernels.h -- KdNode::Build (Src/KdTree.cpp:37-126) on the device, with the reference's split decisions, and the layouts
+// derived from the tree (leaf records, the explicit-link copy, the flat hierarchy).  Included inside rtw_device.hip's anonymous namespace.
+//
+// The reference's recursion, level by level: a node is its segment [start, start + count) of the triangle order.  One wave per node:
+//   bounds      min / max over the segment's vertices (order-free, exact)
+//   mid point   sum of (v0 + v1 + v2) / 3.0f over the segment IN LIST ORDER, fp32, then / count: the wave computes 64 centroids at a time
+//               in parallel and one dependent chain of adds folds them in order (v_readlane), exactly the reference's sequence
+//   axis        GetLargestAxisOfBounds' `>` cascade (ties go to Z, then Y)
+//   partition   stable: left iff centroid[axis] < mid[axis] (strict), both sides keep the list order (ballot + prefix counts);
+//               a one-sided split becomes first half / second half of the current order
+// A subtree over n triangles holds 2 n - 1 nodes, so preorder numbers need no second pass: left child = i + 1, right child =
+// i + 2 n_left, skip = i + 2 n - 1; the stable partitions leave the triangles in preorder leaf order, so a leaf's slot is its segment start.
+
+struct BuildNode { int32_t start, count, index, depth; };
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) { const float w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) { const float w = __shfl_xor(v, o); v = w > v ? w : v; } return v; }
+
+__device__ __forceinline__ f3 build_centroid(const float* __restrict__ pts, const int32_t* __restrict__ idx, int tri)
+{
+    const int a = idx[tri * 3], b = idx[tri * 3 + 1], c = idx[tri * 3 + 2];
+    const f3 pa = mk(pts[a * 3], pts[a * 3 + 1], pts[a * 3 + 2]), pb = mk(pts[b * 3], pts[b * 3 + 1], pts[b * 3 + 2]), pc = mk(pts[c * 3], pts[c * 3 + 1], pts[c * 3 + 2]);
+    const f3 s = (pa + pb) + pc;
+    return mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
+}
+
+// the zero (its sign) the segment's vertices show first on axis `a`, in the order the reference expands its box: triangle by triangle, p0 p1 p2
+// (whole wave; only called when the box's bound on that axis is a zero)
+__device__ __forceinline__ float build_first_zero(const float* __restrict__ pts, const int32_t* __restrict__ idx, const int32_t* __restrict__ order, int start, int n, int a)
+{
+    int first = 0x7FFFFFFF;
+    for (int t = lane_id(); t < n && first == 0x7FFFFFFF; t += 64) {
+        const int tri = order[start + t];
+        for (int k = 0; k < 3; k++) if (pts[idx[tri * 3 + k] * 3 + a] == 0.0f) { first = t * 3 + k; break; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(first, o); first = w < first ? w : first; }
+    if (first == 0x7FFFFFFF) return 0.0f;
+    return pts[idx[order[start + first / 3] * 3 + first % 3] * 3 + a];
+}
+
+// one level of the recursion: the nodes of cur[0 .. *n_cur) are split, their children appended to next[]
+__global__ __launch_bounds__(256) void build_level_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ order_src, int32_t* __restrict__ order_dst, int32_t* __restrict__ leaf_order,
+                                                          const BuildNode* __restrict__ cur, const uint32_t* __restrict__ n_cur, BuildNode* __restrict__ next, uint32_t* __restrict__ n_next,
+                                                          RtwNode* __restrict__ nodes, int32_t* __restrict__ node_depth, uint32_t* __restrict__ level_count)
+{
+    const uint32_t nn = *n_cur;
+    const int lane = lane_id();
+    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t w = wave0; w < nn; w += nwaves) {
+        const BuildNode nd = cur[w];
+        const int start = nd.start, n = nd.count;
+        // ---- bounds (RAabb::Expand over every vertex of the segment) ----
+        float lox = FLT_MAX, loy = FLT_MAX, loz = FLT_MAX, hix = -FLT_MAX, hiy = -FLT_MAX, hiz = -FLT_MAX;
+        for (int t = lane; t < n; t += 64) {
+            const int tri = order_src[start + t];
+            for (int k = 0; k < 3; k++) {
+                const int v = idx[tri * 3 + k];
+                const float x = pts[v * 3], y = pts[v * 3 + 1], z = pts[v * 3 + 2];
+                if (x < lox) lox = x; if (x > hix) hix = x;
+                if (y < loy) loy = y; if (y > hiy) hiy = y;
+                if (z < loz) loz = z; if (z > hiz) hiz = z;
+            }
+        }
+        lox = wave_min(lox); loy = wave_min(loy); loz = wave_min(loz); hix = wave_max(hix); hiy = wave_max(hiy); hiz = wave_max(hiz);
+        // +0 and -0 compare equal: the reference's sequential Expand keeps whichever zero it met FIRST; the parallel reduction may hold the other
+        if (lox == 0.0f) lox = build_first_zero(pts, idx, order_src, start, n, 0);
+        if (loy == 0.0f) loy = build_first_zero(pts, idx, order_src, start, n, 1);
+        if (loz == 0.0f) loz = build_first_zero(pts, idx, order_src, start, n, 2);
+        if (hix == 0.0f) hix = build_first_zero(pts, idx, order_src, start, n, 0);
+        if (hiy == 0.0f) hiy = build_first_zero(pts, idx, order_src, start, n, 1);
+        if (hiz == 0.0f) hiz = build_first_zero(pts, idx, order_src, start, n, 2);
+        RtwNode rec;
+        rec.min_x = lox; rec.min_y = loy; rec.min_z = loz; rec.max_x = hix; rec.max_y = hiy; rec.max_z = hiz;
+        rec.skip = nd.index + 2 * n - 1;
+        if (n == 1) {                    // a leaf: its slot in leaf order is its place in the triangle order
+            const int tri = order_src[start];
+            rec.tri = start;
+            if (lane == 0) { nodes[nd.index] = rec; node_depth[nd.index] = nd.depth; leaf_order[start] = tri; }
+            continue;
+        }
+        rec.tri = -1;
+        // ---- NodeMidPoint: the centroids summed in list order (one chain of dependent adds), then / NumTriangles ----
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        for (int t0 = 0; t0 < n; t0 += 64) {
+            const int cnt = n - t0 < 64 ? n - t0 : 64;
+            f3 c = mk(0, 0, 0);
+            if (lane < cnt) c = build_centroid(pts, idx, order_src[start + t0 + lane]);
+            for (int j = 0; j < cnt; j++) { mx = mx + readlane_f(c.x, j); my = my + readlane_f(c.y, j); mz = mz + readlane_f(c.z, j); }
+        }
+        const float fn = (float)n;
+        mx = mx / fn; my = my / fn; mz = mz / fn;
+        // ---- GetLargestAxisOfBounds ----
+        const float sx = hix - lox, sy = hiy - loy, sz = hiz - loz;
+        const int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);
+        const float cut = axis == 0 ? mx : (axis == 1 ? my : mz);
+        // ---- how many go left ----
+        int n_left = 0;
+        for (int t0 = 0; t0 < n; t0 += 64) {
+            bool left = false;
+            if (t0 + lane < n) { const f3 c = build_centroid(pts, idx, order_src[start + t0 + lane]); const float v = axis == 0 ? c.x : (axis == 1 ? c.y : c.z); left = v < cut; }
+            n_left += (int)__popcll(__ballot(left));
+        }
+        const bool one_sided = n_left == 0 || n_left == n;
+        if (one_sided) n_left = n / 2;
+        // ---- the two sides, each in list order ----
+        int done_l = 0, done_r = 0;
+        for (int t0 = 0; t0 < n; t0 += 64) {
+            const bool mine = t0 + lane < n;
+            const int tri = mine ? order_src[start + t0 + lane] : 0;
+            bool left = false;
+            if (mine) {
+                if (one_sided) left = t0 + lane < n_left;
+                else { const f3 c = build_centroid(pts, idx, tri); const float v = axis == 0 ? c.x : (axis == 1 ? c.y : c.z); left = v < cut; }
+            }
+            const unsigned long long ml = __ballot(mine && left), mr = __ballot(mine && !left);
+            if (mine) {
+                if (left) order_dst[start + done_l + mbcnt(ml)] = tri;
+                else order_dst[start + n_left + done_r + mbcnt(mr)] = tri;
+            }
+            done_l += (int)__popcll(ml); done_r += (int)__popcll(mr);
+        }
+        if (lane == 0) {
+            nodes[nd.index] = rec; node_depth[nd.index] = nd.depth;
+            const uint32_t at = atomicAdd(n_next, 2u);
+            BuildNode l, r;
+            l.start = start; l.count = n_left; l.index = nd.index + 1; l.depth = nd.depth + 1;
+            r.start = start + n_left; r.count = n - n_left; r.index = nd.index + 2 * n_left; r.depth = nd.depth + 1;
+            next[at] = l; next[at + 1] = r;
+            atomicAdd(&level_count[nd.depth + 1 < 63 ? nd.depth + 1 : 63], 2u);
+        }
+    }
+}
+
+// leaf records in leaf order: the triangle with the face normal RRay::TestIntersectionWithTriangle recomputes at every test
+// (Src/RRay.cpp:138-145: normalize(cross(p1 - p0, p2 - p0)), tiny vectors left as they are) and the shading inputs
+// RMeshShape::TestRayIntersection gathers per hit (Src/MeshShape.cpp:303-326)
+__global__ void build_leaf_records_kernel(const float* __restrict__ pts, const float* __restrict__ tcs, const float* __restrict__ nrm,
+                                          const int32_t* __restrict__ idx_p, const int32_t* __restrict__ idx_t, const int32_t* __restrict__ idx_n,
+                                          const int32_t* __restrict__ mat, const int32_t* __restrict__ leaf_order, int n_tris, RtwTri* __restrict__ tris, RtwShade* __restrict__ shade)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_tris) return;
+    const int t = leaf_order[s];
+    const int a = idx_p[t * 3], b = idx_p[t * 3 + 1], c = idx_p[t * 3 + 2];
+    const f3 p0 = mk(pts[a * 3], pts[a * 3 + 1], pts[a * 3 + 2]), p1 = mk(pts[b * 3], pts[b * 3 + 1], pts[b * 3 + 2]), p2 = mk(pts[c * 3], pts[c * 3 + 1], pts[c * 3 + 2]);
+    const f3 n = normalized(cross(p1 - p0, p2 - p0));
+    RtwTri r;
+    r.p0x = p0.x; r.p0y = p0.y; r.p0z = p0.z; r.nx = n.x;
+    r.p1x = p1.x; r.p1y = p1.y; r.p1z = p1.z; r.ny = n.y;
+    r.p2x = p2.x; r.p2y = p2.y; r.p2z = p2.z; r.nz = n.z;
+    r.d1 = dot(n, p0); r.orig = t; r.pad0 = r.pad1 = 0;
+    tris[s] = r;
+    RtwShade sh;
+    const int na = idx_n[t * 3], nb = idx_n[t * 3 + 1], nc = idx_n[t * 3 + 2], ta = idx_t[t * 3], tb = idx_t[t * 3 + 1], tc = idx_t[t * 3 + 2];
+    sh.n0x = nrm[na * 3]; sh.n0y = nrm[na * 3 + 1]; sh.n0z = nrm[na * 3 + 2];
+    sh.n1x = nrm[nb * 3]; sh.n1y = nrm[nb * 3 + 1]; sh.n1z = nrm[nb * 3 + 2];
+    sh.n2x = nrm[nc * 3]; sh.n2y = nrm[nc * 3 + 1]; sh.n2z = nrm[nc * 3 + 2];
+    sh.u0 = tcs[ta * 3]; sh.v0 = tcs[ta * 3 + 1]; sh.u1 = tcs[tb * 3]; sh.v1 = tcs[tb * 3 + 1]; sh.u2 = tcs[tc * 3]; sh.v2 = tcs[tc * 3 + 1];
+    sh.material = mat[t];
+    shade[s] = sh;
+}
+
+// place[i] of every node in the explicit-link array: the nodes of depth <= D first (preorder), the deeper ones after them (preorder);
+// one block scans the two flags over the preorder index
+__global__ __launch_bounds__(1024) void build_tnode_places_kernel(const int32_t* __restrict__ node_depth, int n_nodes, int depth_limit, int32_t* __restrict__ place, int32_t* __restrict__ n_top_out)
+{
+    __shared__ int part[1024];
+    __shared__ int n_top_sh;
+    // first the number of top nodes
+    int mine = 0;
+    for (int i = threadIdx.x; i < n_nodes; i += 1024) mine += node_depth[i] <= depth_limit ? 1 : 0;
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int k = 0; k < 1024; k++) s += part[k]; n_top_sh = s; *n_top_out = s; }
+    __syncthreads();
+    const int n_top = n_top_sh;
+    // then both running counts over contiguous chunks of the preorder index
+    const int per = (n_nodes + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < n_nodes ? lo + per : n_nodes;
+    int tops = 0;
+    for (int i = lo; i < hi; i++) tops += node_depth[i] <= depth_limit ? 1 : 0;
+    __syncthreads();
+    part[threadIdx.x] = tops;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int k = 0; k < 1024; k++) { const int v = part[k]; part[k] = s; s += v; } }
+    __syncthreads();
+    int t = part[threadIdx.x];            // top nodes before this chunk
+    for (int i = lo; i < hi; i++) {
+        const bool top = node_depth[i] <= depth_limit;
+        place[i] = top ? t : n_top + (i - t);       // deep nodes before i = i - (top nodes before i)
+        t += top ? 1 : 0;
+    }
+    if (threadIdx.x == 0) place[n_nodes] = n_nodes;
+}
+
+__global__ void build_tnodes_kernel(const RtwNode* __restrict__ nodes, const int32_t* __restrict__ place, int n_nodes, RtwPNode* __restrict__ tnodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const RtwNode s = nodes[i];
+    RtwPNode t;
+    t.min_x = s.min_x; t.max_x = s.max_x; t.min_y = s.min_y; t.max_y = s.max_y; t.min_z = s.min_z; t.max_z = s.max_z;
+    t.skip = place[s.skip];
+    t.link = s.tri >= 0 ? s.tri : -1 - place[i + 1];
+    tnodes[place[i]] = t;
+}
+
+// flat hierarchy: level 0 = the leaves' own boxes by slot; level l + 1 entry k = union of level l entries [16 k, 16 k + 16)
+__global__ void build_flat0_kernel(const RtwNode* __restrict__ nodes, int n_nodes, float* __restrict__ flat0)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const RtwNode s = nodes[i];
+    if (s.tri < 0) return;
+    float* e = flat0 + (size_t)s.tri * 6;
+    e[0] = s.min_x; e[1] = s.max_x; e[2] = s.min_y; e[3] = s.max_y; e[4] = s.min_z; e[5] = s.max_z;
+}
+__global__ void build_flat_up_kernel(const float* __restrict__ lower, int n_lower, float* __restrict__ upper, int n_upper)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_upper) return;
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = 16 * k; i < 16 * k + 16 && i < n_lower; i++)
+        for (int c = 0; c < 3; c++) {
+            const float a = lower[(size_t)i * 6 + 2 * c], b = lower[(size_t)i * 6 + 2 * c + 1];
+            if (a < lo[c]) lo[c] = a;
+            if (b > hi[c]) hi[c] = b;
+        }
+    for (int c = 0; c < 3; c++) { upper[(size_t)k * 6 + 2 * c] = lo[c]; upper[(size_t)k * 6 + 2 * c + 1] = hi[c]; }
+}

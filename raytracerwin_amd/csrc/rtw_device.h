@@ -73,12 +73,23 @@ struct GroupTuning {
     bool single_mesh = false, persist = true; // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
     int overflow_hint[32];                   // how many rays that were in the previous group, per round (-1 = unknown)
+    int wide_below = 0; bool wide_ok = false;  // lists between wave_below and wide_below rays run sixteen lanes per ray on the 16-wide tree (all meshes have one)
     int wave_below = 0;                      // a trace round whose list (previous group's length) is shorter than this runs a wave per ray
     bool staged_all = false;                 // ... and that is the shape's whole tree
     int staged_shape = -1, staged_top = 0;   // the trace blocks stage the first staged_top tnodes records of this shape in LDS (-1: nothing staged)
     hipEvent_t* timing = nullptr;  // null, or 4 events: before the primary kernel, after it, after the bounce rounds, after resolve
 };
 int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwGroupParams& g, const GroupTuning& tune, bool stats, hipStream_t stream);
+// ---- KdNode::Build and the layouts derived from the tree, on the device (rtw_build_kernels.h) ----
+struct DeviceBuildIn {      // the arrays RMeshShape owns (host memory)
+    const float* points; int n_points; const float* texcoords; int n_texcoords; const float* normals; int n_normals;
+    const int32_t* idx_p; const int32_t* idx_t; const int32_t* idx_n; const int32_t* tri_material; int n_tris;
+};
+struct DeviceBuildOut {     // device memory, the caller's from here on (hipFree)
+    RtwNode* nodes; RtwPNode* tnodes; RtwTri* tris; RtwShade* shade; float* flat[3];
+    int n_nodes, tnodes_top, max_depth, flat_n[3], flat_pad[3];
+};
+int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* out, hipStream_t stream);
 #define RTW_TNODES_TOP_BUDGET 3072 // records (32 B each) of a tree's upper levels a block of the ray-per-lane trace kernel stages in LDS: 96 KiB
 #define RTW_LDS_WIDE_BUDGET 160   // 16-wide nodes (448 B each) that may be staged in LDS: 70 KiB -> two 256-thread blocks per CU
 #define RTW_LDS_QUAD_BUDGET 1024  // quads (128 B each) that may be staged in LDS beside the per-quartet trails and lists

@@ -13,6 +13,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <cstring>
 
 #include "rtw_types.h"
 #ifndef RTW_HOST_EMUL
@@ -1840,6 +1843,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restric
 #ifndef RTW_HOST_EMUL
 #include "rtw_wave_kernels.h"
 #include "rtw_group_kernels.h"
+#include "rtw_build_kernels.h"
 #endif
 
 __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
@@ -2318,7 +2322,13 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                     if (tune.has_analytic) { if (stats) RTW_LAUNCH_GT(true, true, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, true, NT_, CAP_, STG, BLOCKS, DYN); } \
                     else { if (stats) RTW_LAUNCH_GT(true, false, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, false, NT_, CAP_, STG, BLOCKS, DYN); } \
                 } while (0)
-                if (!tune.carry && tune.round_hint[r - 1] >= 0 && tune.round_hint[r - 1] < tune.wave_below) {
+                if (!tune.has_analytic && tune.wide_ok && tune.round_hint[r - 1] >= 0 && tune.round_hint[r - 1] < tune.wide_below && tune.round_hint[r - 1] >= tune.wave_below) {
+                    // a medium list: sixteen lanes per ray on the 16-wide tree
+                    long long blocks = ((long long)tune.round_hint[r - 1] + tune.round_hint[r - 1] / 4 + 256 + 15) / 16;
+                    if (blocks > 262144) blocks = 262144;
+                    if (stats) hipLaunchKernelGGL(gtrace_wide_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, sc, gb, r - 1);
+                    else hipLaunchKernelGGL(gtrace_wide_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, sc, gb, r - 1);
+                } else if (!tune.carry && tune.round_hint[r - 1] >= 0 && tune.round_hint[r - 1] < tune.wave_below) {
                     // a short list: a wave per ray (128-thread blocks, a wave takes rays in turn)
                     constexpr int NTV = 128;
                     long long blocks = ((long long)tune.round_hint[r - 1] + tune.round_hint[r - 1] / 4 + 64 + NTV / 64 - 1) / (NTV / 64);
@@ -2399,6 +2409,105 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     if (tune.timing) (void)hipEventRecord(tune.timing[3], stream);
     return (int)hipGetLastError();
 }
+
+// ---- KdNode::Build + derived layouts on the device (rtw_build_kernels.h) ------------------------------------------------------
+namespace {
+__global__ void build_iota_kernel(int32_t* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
+struct TempBufs {
+    std::vector<void*> v;
+    ~TempBufs() { for (void* p : v) (void)hipFree(p); }
+    template <typename T> hipError_t get(T** out, size_t count) { void* d = nullptr; const hipError_t e = hipMalloc(&d, (count ? count : 1) * sizeof(T)); if (e == hipSuccess) v.push_back(d); *out = (T*)d; return e; }
+};
+}  // namespace
+
+#define RTW_HIP_OK(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* out, hipStream_t stream)
+{
+    const int n = in.n_tris, n_nodes = 2 * n - 1;
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    TempBufs tmp;
+    float *d_pts, *d_tcs, *d_nrm; int32_t *d_ip, *d_it, *d_in, *d_mat, *d_ord[2], *d_leaf, *d_depth, *d_place, *d_ntop;
+    BuildNode* d_lvl[2]; uint32_t* d_cnt;      // d_cnt[0..1]: node counts of the two level lists, d_cnt[2..65]: nodes per depth
+    RTW_HIP_OK(tmp.get(&d_pts, (size_t)in.n_points * 3)); RTW_HIP_OK(tmp.get(&d_tcs, (size_t)in.n_texcoords * 3)); RTW_HIP_OK(tmp.get(&d_nrm, (size_t)in.n_normals * 3));
+    RTW_HIP_OK(tmp.get(&d_ip, (size_t)n * 3)); RTW_HIP_OK(tmp.get(&d_it, (size_t)n * 3)); RTW_HIP_OK(tmp.get(&d_in, (size_t)n * 3)); RTW_HIP_OK(tmp.get(&d_mat, (size_t)n));
+    RTW_HIP_OK(tmp.get(&d_ord[0], (size_t)n)); RTW_HIP_OK(tmp.get(&d_ord[1], (size_t)n)); RTW_HIP_OK(tmp.get(&d_leaf, (size_t)n));
+    RTW_HIP_OK(tmp.get(&d_depth, (size_t)n_nodes)); RTW_HIP_OK(tmp.get(&d_place, (size_t)n_nodes + 1)); RTW_HIP_OK(tmp.get(&d_ntop, 1));
+    RTW_HIP_OK(tmp.get(&d_lvl[0], (size_t)n + 2)); RTW_HIP_OK(tmp.get(&d_lvl[1], (size_t)n + 2)); RTW_HIP_OK(tmp.get(&d_cnt, 66));
+    RTW_HIP_OK(hipMemcpyAsync(d_pts, in.points, (size_t)in.n_points * 12, hipMemcpyHostToDevice, stream));
+    RTW_HIP_OK(hipMemcpyAsync(d_tcs, in.texcoords, (size_t)in.n_texcoords * 12, hipMemcpyHostToDevice, stream));
+    RTW_HIP_OK(hipMemcpyAsync(d_nrm, in.normals, (size_t)in.n_normals * 12, hipMemcpyHostToDevice, stream));
+    RTW_HIP_OK(hipMemcpyAsync(d_ip, in.idx_p, (size_t)n * 12, hipMemcpyHostToDevice, stream));
+    RTW_HIP_OK(hipMemcpyAsync(d_it, in.idx_t, (size_t)n * 12, hipMemcpyHostToDevice, stream));
+    RTW_HIP_OK(hipMemcpyAsync(d_in, in.idx_n, (size_t)n * 12, hipMemcpyHostToDevice, stream));
+    RTW_HIP_OK(hipMemcpyAsync(d_mat, in.tri_material, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    // outputs (owned by the caller afterwards)
+    DeviceBuildOut o; std::memset(&o, 0, sizeof o);
+    o.n_nodes = n_nodes;
+    RTW_HIP_OK(hipMalloc((void**)&o.nodes, (size_t)n_nodes * sizeof(RtwNode)));
+    RTW_HIP_OK(hipMalloc((void**)&o.tnodes, (size_t)n_nodes * sizeof(RtwPNode)));
+    RTW_HIP_OK(hipMalloc((void**)&o.tris, (size_t)n * sizeof(RtwTri)));
+    RTW_HIP_OK(hipMalloc((void**)&o.shade, (size_t)n * sizeof(RtwShade)));
+    {
+        int cnt = n;
+        for (int l = 0; l < 3; l++) {
+            o.flat_n[l] = cnt; o.flat_pad[l] = ((cnt + 63) / 64) * 64 + 64;
+            RTW_HIP_OK(hipMalloc((void**)&o.flat[l], (size_t)o.flat_pad[l] * 24));
+            RTW_HIP_OK(hipMemsetAsync(o.flat[l], 0, (size_t)o.flat_pad[l] * 24, stream));
+            cnt = (cnt + 15) / 16;
+        }
+    }
+    // the recursion, level by level
+    hipLaunchKernelGGL(build_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_ord[0], n);
+    RTW_HIP_OK(hipMemsetAsync(d_cnt, 0, 66 * 4, stream));
+    {
+        const BuildNode root = { 0, n, 0, 0 };
+        const uint32_t one = 1u;
+        RTW_HIP_OK(hipMemcpyAsync(d_lvl[0], &root, sizeof root, hipMemcpyHostToDevice, stream));
+        RTW_HIP_OK(hipMemcpyAsync(&d_cnt[0], &one, 4, hipMemcpyHostToDevice, stream));
+        RTW_HIP_OK(hipMemcpyAsync(&d_cnt[2], &one, 4, hipMemcpyHostToDevice, stream));
+        RTW_HIP_OK(hipStreamSynchronize(stream));       // (root / one live on this frame)
+    }
+    int level = 0;
+    for (;;) {
+        for (int k = 0; k < 8; k++, level++) {          // eight levels per read-back
+            const int c = level & 1;
+            RTW_HIP_OK(hipMemsetAsync(&d_cnt[1 - c], 0, 4, stream));
+            // a wave per node; at most n nodes on a level, the stride loop takes any excess
+            unsigned blocks = (unsigned)(((long long)(n < (1 << level) || level > 20 ? n : (1 << level)) + 3) / 4);
+            if (blocks > 8192u) blocks = 8192u;
+            if (blocks < 1u) blocks = 1u;
+            hipLaunchKernelGGL(build_level_kernel, dim3(blocks), dim3(256), 0, stream, d_pts, d_ip, d_ord[c], d_ord[1 - c], d_leaf, d_lvl[c], &d_cnt[c], d_lvl[1 - c], &d_cnt[1 - c],
+                               o.nodes, d_depth, &d_cnt[2]);
+        }
+        uint32_t left = 0;
+        RTW_HIP_OK(hipMemcpyAsync(&left, &d_cnt[level & 1], 4, hipMemcpyDeviceToHost, stream));
+        RTW_HIP_OK(hipStreamSynchronize(stream));
+        if (left == 0u) break;
+        if (level > 4 * n + 64) return (int)hipErrorUnknown;        // cannot happen: every level splits every segment
+    }
+    // depth statistics -> how many levels fit the LDS budget of the trace kernels (the host build's rule)
+    uint32_t per_level[64];
+    RTW_HIP_OK(hipMemcpyAsync(per_level, &d_cnt[2], sizeof per_level, hipMemcpyDeviceToHost, stream));
+    RTW_HIP_OK(hipStreamSynchronize(stream));
+    int D = -1, count = 0, deepest = 0;
+    for (int d = 0; d < 64; d++) if (per_level[d] > 0) deepest = d;
+    for (int d = 0; d < 64; d++) { if (per_level[d] == 0 || count + (int)per_level[d] > top_budget) break; count += (int)per_level[d]; D = d; }
+    o.max_depth = deepest + 1;
+    hipLaunchKernelGGL(build_tnode_places_kernel, dim3(1), dim3(1024), 0, stream, d_depth, n_nodes, D, d_place, d_ntop);
+    hipLaunchKernelGGL(build_tnodes_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, o.nodes, d_place, n_nodes, o.tnodes);
+    hipLaunchKernelGGL(build_leaf_records_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_pts, d_tcs, d_nrm, d_ip, d_it, d_in, d_mat, d_leaf, n, o.tris, o.shade);
+    hipLaunchKernelGGL(build_flat0_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, o.nodes, n_nodes, o.flat[0]);
+    for (int l = 1; l < 3; l++)
+        hipLaunchKernelGGL(build_flat_up_kernel, dim3((o.flat_n[l] + 255) / 256), dim3(256), 0, stream, o.flat[l - 1], o.flat_n[l - 1], o.flat[l], o.flat_n[l]);
+    int32_t ntop = 0;
+    RTW_HIP_OK(hipMemcpyAsync(&ntop, d_ntop, 4, hipMemcpyDeviceToHost, stream));
+    RTW_HIP_OK(hipStreamSynchronize(stream));
+    RTW_HIP_OK(hipGetLastError());
+    o.tnodes_top = D < 0 ? 0 : ntop;
+    *out = o;
+    return 0;
+}
+#undef RTW_HIP_OK
 
 #ifdef RTW_TIMING
 int read_timing(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rtw_timing), sizeof(unsigned long long) * (size_t)n); }

@@ -139,7 +139,9 @@ struct rtw_context {
     int visit_budget = 256;             // one-mesh scenes with a big tree: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
     int group_paths = 4 << 20;          // passes are grouped until a launch holds about this many paths ...
     int group_max = 64;                 // ... and at most this many passes (a power of two)
-    int wave_below = 100000;            // trace rounds with fewer rays than this (previous group's count) run a wave per ray instead of a ray per lane
+    int wide_below = 0;                 // trace rounds with at least wave_below and fewer than this many rays run sixteen lanes per ray on the 16-wide tree (0: never)
+    int wave_below = 160000;            // trace rounds with fewer rays than this (previous group's count) run a wave per ray instead of a ray per lane
+    int device_build = 1;               // rtw_scene_commit builds the tree (KdNode::Build's decisions) and the layouts derived from it on the device (0: on the host)
     int trace_persist = 1;              // one-mesh scenes: persistent trace waves that refill their lanes
     int trace_stage = 1;                // the ray-per-lane trace kernel stages the first mesh's upper tree levels in LDS (1024-thread blocks)
     int last_pipeline = -1;             // the pipeline the latest render call actually ran (rtw_last_pass_pipeline)
@@ -295,7 +297,9 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         return RTW_OK;
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "wide_below") == 0) { ctx->wide_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "device_build") == 0) { ctx->device_build = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "trace_persist") == 0) { ctx->trace_persist = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "trace_stage") == 0) { ctx->trace_stage = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
@@ -608,11 +612,39 @@ int rtw_scene_commit(rtw_scene* scene)
     bool textured_mesh_before = false;
     for (size_t s = 0; s < scene->meshes.size(); s++) {
         rtw::HostMesh& m = *scene->meshes[s];
-        rtw::build_tree(m);
-        rtw::build_quads(m);
         RtwShapeDev& d = h->shapes[s];
         int rc;
-        if ((rc = upload(scene, m.nodes, &d.nodes)) != RTW_OK) return rc;
+        const bool on_device = scene->ctx->device_build && m.kind == RTW_SHAPE_MESH && m.n_tris() > 0;
+        if (on_device) {
+            // KdNode::Build's recursion and the layouts derived from the tree run on the device (rtw_build_kernels.h); the host keeps copies of
+            // the small arrays for the screen bins, the older pipelines' collapsed trees and the inspection calls
+            rtw::DeviceBuildIn in;
+            in.points = &m.points[0].x; in.n_points = (int)m.points.size(); in.texcoords = &m.texcoords[0].x; in.n_texcoords = (int)m.texcoords.size();
+            in.normals = &m.normals[0].x; in.n_normals = (int)m.normals.size();
+            in.idx_p = m.point_idx.data(); in.idx_t = m.texcoord_idx.data(); in.idx_n = m.normal_idx.data(); in.tri_material = m.poly_material.data(); in.n_tris = m.n_tris();
+            rtw::DeviceBuildOut o;
+            const hipError_t be = (hipError_t)rtw::device_build_mesh(in, RTW_TNODES_TOP_BUDGET, &o, scene->ctx->stream);
+            if (be != hipSuccess) return hip_fail(be, "device tree build");
+            scene->allocs.push_back(o.nodes); scene->allocs.push_back(o.tnodes); scene->allocs.push_back(o.tris); scene->allocs.push_back(o.shade);
+            for (int l = 0; l < 3; l++) scene->allocs.push_back(o.flat[l]);
+            m.nodes.resize((size_t)o.n_nodes); m.tnodes.resize((size_t)o.n_nodes); m.tris.resize((size_t)in.n_tris); m.shade.resize((size_t)in.n_tris);
+            HIP_TRY(hipMemcpy(m.nodes.data(), o.nodes, m.nodes.size() * sizeof(RtwNode), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(m.tnodes.data(), o.tnodes, m.tnodes.size() * sizeof(RtwPNode), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(m.tris.data(), o.tris, m.tris.size() * sizeof(RtwTri), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(m.shade.data(), o.shade, m.shade.size() * sizeof(RtwShade), hipMemcpyDeviceToHost));
+            m.tnodes_top = o.tnodes_top; m.max_depth = o.max_depth;
+            for (int l = 0; l < 3; l++) {
+                m.flat_n[l] = o.flat_n[l]; m.flat_pad[l] = o.flat_pad[l];
+                m.flat[l].resize((size_t)6 * (size_t)o.flat_pad[l]);
+                HIP_TRY(hipMemcpy(m.flat[l].data(), o.flat[l], m.flat[l].size() * sizeof(float), hipMemcpyDeviceToHost));
+                d.flat[l] = o.flat[l]; d.flat_n[l] = o.flat_n[l]; d.flat_pad[l] = o.flat_pad[l];
+            }
+            d.nodes = o.nodes; d.tnodes = o.tnodes; d.tnodes_top = o.tnodes_top; d.tris = o.tris; d.shade = o.shade;
+        } else {
+            rtw::build_tree(m);
+        }
+        rtw::build_quads(m);
+        if (!on_device && (rc = upload(scene, m.nodes, &d.nodes)) != RTW_OK) return rc;
         if (m.quad_depth <= RTW_QUAD_STACK) {
             if ((rc = upload(scene, m.quads, &d.quads)) != RTW_OK) return rc;
             d.n_quads = (int)m.quads.size(); d.quad_depth = m.quad_depth;
@@ -621,16 +653,18 @@ int rtw_scene_commit(rtw_scene* scene)
             if ((rc = upload(scene, m.wides, &d.wides)) != RTW_OK) return rc;
             d.n_wides = (int)m.wides.size(); d.wide_depth = m.wide_depth;
         }
-        rtw::build_tnodes(m, RTW_TNODES_TOP_BUDGET);
-        if ((rc = upload(scene, m.tnodes, &d.tnodes)) != RTW_OK) return rc;
-        d.tnodes_top = m.tnodes_top;
-        rtw::build_flat(m);
-        for (int l = 0; l < 3; l++) {
-            if ((rc = upload(scene, m.flat[l], &d.flat[l])) != RTW_OK) return rc;
-            d.flat_n[l] = m.flat_n[l]; d.flat_pad[l] = m.flat_pad[l];
+        if (!on_device) {
+            rtw::build_tnodes(m, RTW_TNODES_TOP_BUDGET);
+            if ((rc = upload(scene, m.tnodes, &d.tnodes)) != RTW_OK) return rc;
+            d.tnodes_top = m.tnodes_top;
+            rtw::build_flat(m);
+            for (int l = 0; l < 3; l++) {
+                if ((rc = upload(scene, m.flat[l], &d.flat[l])) != RTW_OK) return rc;
+                d.flat_n[l] = m.flat_n[l]; d.flat_pad[l] = m.flat_pad[l];
+            }
+            if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
+            if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
         }
-        if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
-        if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
         std::vector<uint32_t> atlas;
         for (size_t t = 0; t < m.textures.size() && t < RTW_DEV_MAX_TEXTURES; t++) {
             const rtw::HostTexture& tx = m.textures[t];
@@ -1179,7 +1213,10 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.persist = cx->trace_persist != 0;
     // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
     tune.visit_budget = (cx->visit_budget > 0 && tune.single_mesh && scene->meshes[0]->nodes.size() > 4096) ? cx->visit_budget : INT32_MAX;
-    tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 3 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
+    tune.wide_below = cx->wide_below;
+    tune.wide_ok = true;
+    for (const auto& m : scene->meshes) if (m->kind == RTW_SHAPE_MESH && (m->wides.empty() || m->wide_depth > RTW_WIDE_STACK || m->wides.size() >= 65536)) tune.wide_ok = false;
+    tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 5 / 2 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
     tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
     // (keyed by the launch shape WITHOUT the number of passes: the lengths are kept per pass and scaled to the group at hand, so a warm-up call of any

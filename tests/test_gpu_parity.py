@@ -763,3 +763,70 @@ def test_full_size_frames_bit_exact_vs_oracle(ctx, oracle_mod, cfg, mesh, W, H, 
     fb.close()
     assert (argb == ob).all()
     assert (bits(accum) == bits(oa)).all()
+
+
+# ---- KdNode::Build on the device -------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MESHES)
+def test_device_built_tree_equals_the_references(ctx, name):
+    """rtw_scene_commit builds the tree on the device (rtw_build_kernels.h: the reference's split decisions -- fp32 centroid mean in list order,
+    strict `<`, the axis `>` cascade, the half / half fallback -- level by level, a wave per node).  Its preorder bounds and leaf order are those of
+    the reference's own KdNode::Build (mesh_*.npz: dumped from the reference's pointer tree), bit for bit, and every derived layout (flat
+    hierarchy levels, collapsed trees, screen bins) equals what the host build of the same mesh derives."""
+    g = np.load(os.path.join(GOLDEN, "mesh_%s.npz" % name))
+    out = {}
+    for dev in (1, 0):
+        ctx.set_option("device_build", dev)
+        s = R.RayTracerScene(ctx)
+        s.AddShape(R.RMeshShape.Create(asset(name + ".obj")), R.SurfaceMaterial_Diffuse())
+        s.commit()
+        b, skip, tri = s.mesh_nodes()
+        assert (bits(b) == bits(g["tree_bounds"])).all() and (tri == g["tree_tri"]).all(), dev
+        out[dev] = dict(skip=skip, depth=s.mesh_info()["max_depth"], flat=[s.mesh_flat(l) for l in range(3)], quads=s.mesh_quads(),
+                        bins=s.mesh_bins(1920, 1080, 16, 4), bins2=s.mesh_bins(333, 217, 16, 4))
+        s.close()
+    ctx.set_option("device_build", 1)
+    d, h = out[1], out[0]
+    assert (d["skip"] == h["skip"]).all() and d["depth"] == h["depth"]
+    for l in range(3):
+        assert (bits(d["flat"][l]) == bits(h["flat"][l])).all(), l
+    assert (bits(d["quads"][0]) == bits(h["quads"][0])).all() and (d["quads"][1] == h["quads"][1]).all()
+    for k in ("bins", "bins2"):
+        assert (d[k][0] == h[k][0]).all() and (d[k][1] == h[k][1]).all()
+
+
+@pytest.mark.gpu
+def test_device_built_trees_of_awkward_meshes_render_like_host_built_ones(ctx):
+    """triangle soups that exercise the split rules' corners (coincident centroids -> one-sided splits -> half / half, degenerate and axis-aligned
+    triangles, a single triangle): same tree either way, same frames"""
+    rng = np.random.default_rng(5)
+    def soup(n, kind):
+        if kind == "same":          # every centroid equal: every split is one-sided
+            base = rng.random((1, 3, 3)).astype(np.float32)
+            pts = np.repeat(base, n, 0)
+        elif kind == "line":        # geometric spacing: very unbalanced splits, a deep tree
+            pts = (rng.random((n, 3, 3)).astype(np.float32) * 0.01)
+            pts[:, :, 0] += (1.5 ** -np.arange(n, dtype=np.float32))[:, None]
+        else:
+            pts = (rng.random((n, 3, 3)).astype(np.float32) - 0.5) * 2
+            pts[::7, :, 2] = pts[::7, :1, 2]          # axis-aligned
+            pts[::11, 2] = pts[::11, 1]               # degenerate
+        p = pts.reshape(-1, 3)
+        i = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+        nrm = np.tile(np.array([[0, 0, 1]], np.float32), (3 * n, 1))
+        return R.RMeshShape.FromArrays(p, np.zeros_like(p), nrm, i, i, i)
+    for n, kind in ((1, "rand"), (2, "same"), (37, "same"), (40, "line"), (300, "rand"), (1000, "rand")):
+        shape = soup(n, kind)
+        res = {}
+        for dev in (1, 0):
+            ctx.set_option("device_build", dev)
+            s = R.RayTracerScene(ctx)
+            s.AddShape(shape, R.SurfaceMaterial_Diffuse((0.9, 0.8, 0.7)))
+            s.commit()
+            b, skip, tri = s.mesh_nodes()
+            a, argb = render_frame(ctx, s, 160, 90, 2, 3, 0, 11)
+            res[dev] = (b, skip, tri, a, argb)
+            s.close()
+        ctx.set_option("device_build", 1)
+        for x, y in zip(res[1], res[0]):
+            assert (bits(x) == bits(y)).all() if x.dtype == np.float32 else (x == y).all(), (n, kind)
