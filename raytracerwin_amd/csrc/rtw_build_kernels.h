@@ -229,3 +229,112 @@ __global__ void build_flat_up_kernel(const float* __restrict__ lower, int n_lowe
         }
     for (int c = 0; c < 3; c++) { upper[(size_t)k * 6 + 2 * c] = lo[c]; upper[(size_t)k * 6 + 2 * c + 1] = hi[c]; }
 }
+
+// ---- screen-space bins of the reference's fixed camera, built on the device ---------------------------------------------------------
+// The host routine (scene_host.cpp build_bins) operation for operation, in double precision: a leaf is listed in the bins its triangle's
+// projection (grown by the jitter margin) touches when the triangle faces the camera by the reference's own float test.  Three passes:
+// count per bin, scan, fill (any order), then every bin's list sorted ascending = preorder.
+struct BinsGeom { int width, height, bin_w, bin_h, bx, by; double margin; };
+
+// the bins of one leaf: calls f(bin) for every bin the leaf is listed in; returns false when the MESH gets no bins at all
+template <typename F>
+__device__ __forceinline__ bool bins_of_leaf(const RtwNode& nd, const RtwTri& t, const BinsGeom& g, F f)
+{
+    const double cx = (double)(g.width / 2), cy = (double)(g.height / 2), H = (double)g.height;
+    const double zmax = (double)nd.max_z - 7.0;
+    if (!(zmax < -0.01)) return false;                      // not wholly in front of the camera
+    {
+        const float ox = 0.0f, oy = 0.0f, oz = 7.0f;
+        const float d0 = t.nx * ox + t.ny * oy + t.nz * oz;
+        const float d2 = d0 - t.d1;
+        if (d2 < 0) return true;                            // faces away from every camera ray: listed nowhere
+    }
+    const double vx[3] = { t.p0x, t.p1x, t.p2x }, vy[3] = { t.p0y, t.p1y, t.p2y }, vz[3] = { t.p0z, t.p1z, t.p2z };
+    double sx[3], sy[3];
+    bool finite = true;
+    for (int k = 0; k < 3; k++) {
+        const double qz = vz[k] - 7.0;
+        sx[k] = cx + H * vx[k] / qz; sy[k] = cy + H * vy[k] / qz;
+        finite = finite && sx[k] == sx[k] && sy[k] == sy[k] && fabs(sx[k]) < 1e12 && fabs(sy[k]) < 1e12;
+    }
+    if (!finite) return false;
+    const double xa = fmin(sx[0], fmin(sx[1], sx[2])), xb = fmax(sx[0], fmax(sx[1], sx[2]));
+    const double ya = fmin(sy[0], fmin(sy[1], sy[2])), yb = fmax(sy[0], fmax(sy[1], sy[2]));
+    double fx0 = floor(xa - g.margin), fx1 = ceil(xb + g.margin), fy0 = floor(ya - g.margin), fy1 = ceil(yb + g.margin);
+    if (fx1 < 0 || fy1 < 0 || fx0 > g.width - 1 || fy0 > g.height - 1) return true;      // off screen
+    if (fx0 < 0) fx0 = 0;
+    if (fy0 < 0) fy0 = 0;
+    if (fx1 > g.width - 1) fx1 = g.width - 1;
+    if (fy1 > g.height - 1) fy1 = g.height - 1;
+    const int bx0 = (int)fx0 / g.bin_w, bx1 = (int)fx1 / g.bin_w, by0 = (int)fy0 / g.bin_h, by1 = (int)fy1 / g.bin_h;
+    const double area2 = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0]);
+    const double scale = fabs(xb - xa) + fabs(yb - ya) + 1.0;
+    const bool use_edges = fabs(area2) > 1e-9 * scale * scale;
+    for (int yb_ = by0; yb_ <= by1; yb_++) {
+        for (int xb_ = bx0; xb_ <= bx1; xb_++) {
+            bool separated = false;
+            if (use_edges) {
+                const double rx0 = (double)(xb_ * g.bin_w) - g.margin, rx1 = (double)(xb_ * g.bin_w + g.bin_w - 1) + g.margin;
+                const double ry0 = (double)(yb_ * g.bin_h) - g.margin, ry1 = (double)(yb_ * g.bin_h + g.bin_h - 1) + g.margin;
+                for (int e = 0; e < 3 && !separated; e++) {
+                    const int a = e, b2 = (e + 1) % 3, c = (e + 2) % 3;
+                    double nx = sy[b2] - sy[a], ny = -(sx[b2] - sx[a]);
+                    if (nx * (sx[c] - sx[a]) + ny * (sy[c] - sy[a]) > 0) { nx = -nx; ny = -ny; }
+                    const double len = sqrt(nx * nx + ny * ny);
+                    if (!(len > 0)) continue;
+                    const double px = nx > 0 ? rx0 : rx1, py = ny > 0 ? ry0 : ry1;
+                    if ((nx * (px - sx[a]) + ny * (py - sy[a])) / len > 1e-6) separated = true;
+                }
+            }
+            if (!separated) f(yb_ * g.bx + xb_);
+        }
+    }
+    return true;
+}
+
+// pass 0: counts[bin] += 1 per listed leaf; pass 1: entries at off[bin] + (a ticket from fill[bin])
+template <int PASS>
+__global__ void bins_pass_kernel(const RtwNode* __restrict__ nodes, const RtwTri* __restrict__ tris, int n_nodes, BinsGeom g,
+                                 uint32_t* __restrict__ counts, const uint32_t* __restrict__ off, uint32_t* __restrict__ ent, uint32_t* __restrict__ no_bins)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const RtwNode nd = nodes[i];
+    if (nd.tri < 0) return;
+    const RtwTri t = tris[nd.tri];
+    const bool ok = bins_of_leaf(nd, t, g, [&](int bin) {
+        if (PASS == 0) atomicAdd(&counts[bin], 1u);
+        else ent[off[bin] + atomicAdd(&counts[bin], 1u)] = (uint32_t)i;
+    });
+    if (!ok) *no_bins = 1u;
+}
+
+// exclusive scan of counts[0..n) into off[0..n], off[n] = total; counts zeroed for the fill pass (one block)
+__global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ counts, uint32_t* __restrict__ off, int n)
+{
+    __shared__ uint32_t part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = t; t += v; } off[n] = t; }
+    __syncthreads();
+    uint32_t t = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) { off[i] = t; t += counts[i]; counts[i] = 0u; }
+}
+
+// every bin's entries ascending (node index = preorder); lists are short: a lane per bin, insertion sort
+__global__ void bins_sort_kernel(const uint32_t* __restrict__ off, uint32_t* __restrict__ ent, int n_bins)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins) return;
+    const uint32_t lo = off[b], hi = off[b + 1];
+    for (uint32_t i = lo + 1; i < hi; i++) {
+        const uint32_t v = ent[i];
+        uint32_t j = i;
+        while (j > lo && ent[j - 1] > v) { ent[j] = ent[j - 1]; j--; }
+        ent[j] = v;
+    }
+}

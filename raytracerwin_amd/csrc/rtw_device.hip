@@ -2507,6 +2507,41 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
     *out = o;
     return 0;
 }
+// Screen bins of one mesh on the device.  *off_out (n_bins + 1 offsets) and *ent_out are the caller's (hipFree); h_off receives the offsets
+// (the host sorts the tiles by list length).  Returns 0 and *has_bins = 0 when the mesh gets no bins (as build_bins returns false).
+int device_build_bins(const RtwNode* d_nodes, const RtwTri* d_tris, int n_nodes, int width, int height, int bin_w, int bin_h,
+                      uint32_t** off_out, uint32_t** ent_out, uint32_t* h_off, int* has_bins, hipStream_t stream)
+{
+    BinsGeom g; g.width = width; g.height = height; g.bin_w = bin_w; g.bin_h = bin_h;
+    g.bx = (width + bin_w - 1) / bin_w; g.by = (height + bin_h - 1) / bin_h;
+    g.margin = 1.0 + 1.25 * (double)height / (2.0 * (double)width);
+    const int n_bins = g.bx * g.by;
+    *off_out = nullptr; *ent_out = nullptr; *has_bins = 0;
+    TempBufs tmp;
+    uint32_t *d_counts, *d_flag;
+    RTW_HIP_OK(tmp.get(&d_counts, (size_t)n_bins)); RTW_HIP_OK(tmp.get(&d_flag, 1));
+    uint32_t* d_off = nullptr;
+    RTW_HIP_OK(hipMalloc((void**)&d_off, ((size_t)n_bins + 1) * 4));
+    RTW_HIP_OK(hipMemsetAsync(d_counts, 0, (size_t)n_bins * 4, stream));
+    RTW_HIP_OK(hipMemsetAsync(d_flag, 0, 4, stream));
+    const unsigned nb = (unsigned)((n_nodes + 255) / 256);
+    hipLaunchKernelGGL(bins_pass_kernel<0>, dim3(nb), dim3(256), 0, stream, d_nodes, d_tris, n_nodes, g, d_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_flag);
+    hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, stream, d_counts, d_off, n_bins);
+    uint32_t flag = 0;
+    RTW_HIP_OK(hipMemcpyAsync(h_off, d_off, ((size_t)n_bins + 1) * 4, hipMemcpyDeviceToHost, stream));
+    RTW_HIP_OK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream));
+    RTW_HIP_OK(hipStreamSynchronize(stream));
+    if (flag != 0u) { (void)hipFree(d_off); return 0; }
+    const uint32_t total = h_off[n_bins];
+    uint32_t* d_ent = nullptr;
+    RTW_HIP_OK(hipMalloc((void**)&d_ent, ((size_t)total + 1) * 4));
+    hipLaunchKernelGGL(bins_pass_kernel<1>, dim3(nb), dim3(256), 0, stream, d_nodes, d_tris, n_nodes, g, d_counts, (const uint32_t*)d_off, d_ent, d_flag);
+    hipLaunchKernelGGL(bins_sort_kernel, dim3((unsigned)((n_bins + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)d_off, d_ent, n_bins);
+    RTW_HIP_OK(hipStreamSynchronize(stream));
+    RTW_HIP_OK(hipGetLastError());
+    *off_out = d_off; *ent_out = d_ent; *has_bins = 1;
+    return 0;
+}
 #undef RTW_HIP_OK
 
 #ifdef RTW_TIMING

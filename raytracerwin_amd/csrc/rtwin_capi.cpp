@@ -160,6 +160,8 @@ struct rtw_scene {
     int traversal = 1;
     RtwSceneDev* d_scene = nullptr;
     std::vector<void*> allocs;
+    std::vector<const RtwNode*> d_nodes_of;     // per shape: the device-built tree and leaf records (null: built on the host)
+    std::vector<const RtwTri*> d_tris_of;
     // screen-space bins of the reference camera, one set per (width, height, bin shape) this scene has been rendered at
     struct JobTable { int task_rows, rank, world, spp; const uint32_t* d_order; int n_jobs, n_busy; };     // n_busy: jobs of tiles with a non-empty bin (they come first)
     // pass-batched pipeline: the launch's tiles split into busy ones (heaviest bins first) and sky-only ones, and the primary kernel's jobs
@@ -640,6 +642,8 @@ int rtw_scene_commit(rtw_scene* scene)
                 d.flat[l] = o.flat[l]; d.flat_n[l] = o.flat_n[l]; d.flat_pad[l] = o.flat_pad[l];
             }
             d.nodes = o.nodes; d.tnodes = o.tnodes; d.tnodes_top = o.tnodes_top; d.tris = o.tris; d.shade = o.shade;
+            scene->d_nodes_of.resize(scene->meshes.size(), nullptr); scene->d_tris_of.resize(scene->meshes.size(), nullptr);
+            scene->d_nodes_of[s] = o.nodes; scene->d_tris_of[s] = o.tris;
         } else {
             rtw::build_tree(m);
         }
@@ -768,7 +772,26 @@ int rtw_scene_mesh_bins(const rtw_scene* scene, int shape, int width, int height
     if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
     if (!counts2) return fail(RTW_ERR_INVALID, "null argument");
     std::vector<uint32_t> off, ent;
-    const bool ok = rtw::build_bins(*scene->meshes[(size_t)shape], width, height, bin_w, bin_h, off, ent);
+    bool ok;
+    if (scene->ctx && scene->ctx->device_build && scene->d_nodes_of.size() > (size_t)shape && scene->d_nodes_of[(size_t)shape]) {
+        // what the renderer uses: the lists built on the device
+        if (width <= 0 || height <= 0 || bin_w <= 0 || bin_h <= 0) return fail(RTW_ERR_INVALID, "bad bin geometry");
+        HIP_TRY(hipSetDevice(scene->ctx->device));
+        const size_t n_bins = (size_t)((width + bin_w - 1) / bin_w) * (size_t)((height + bin_h - 1) / bin_h);
+        off.resize(n_bins + 1);
+        uint32_t *d_off = nullptr, *d_ent = nullptr; int has = 0;
+        const hipError_t be = (hipError_t)rtw::device_build_bins(scene->d_nodes_of[(size_t)shape], scene->d_tris_of[(size_t)shape], (int)scene->meshes[(size_t)shape]->nodes.size(),
+                                                                 width, height, bin_w, bin_h, &d_off, &d_ent, off.data(), &has, scene->ctx->stream);
+        if (be != hipSuccess) return hip_fail(be, "device bins build");
+        ok = has != 0;
+        if (ok) {
+            ent.resize(off.back() ? off.back() : 1, 0u);
+            if (off.back()) HIP_TRY(hipMemcpy(ent.data(), d_ent, (size_t)off.back() * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(d_off); (void)hipFree(d_ent);
+        }
+    } else {
+        ok = rtw::build_bins(*scene->meshes[(size_t)shape], width, height, bin_w, bin_h, off, ent);
+    }
     counts2[0] = ok ? (int64_t)off.size() : 0; counts2[1] = ok ? (int64_t)off.back() : 0;
     if (!ok) return 0;                   // this mesh gets no bins (not wholly in front of the camera, or the frame does not tile)
     if (offsets) std::memcpy(offsets, off.data(), (size_t)std::min<int64_t>(max_offsets, (int64_t)off.size()) * 4);
@@ -942,6 +965,19 @@ static int scene_bins(rtw_scene* scene, int width, int height, int bin_w, int bi
         std::vector<uint32_t> off, ent;
         h[s].off = nullptr; h[s].ent = nullptr;
         if (scene->meshes[s]->kind != RTW_SHAPE_MESH) { for (auto& w : weight) w += 1u; continue; }      // tested by every sample of every tile
+        if (scene->ctx->device_build && scene->d_nodes_of.size() > s && scene->d_nodes_of[s]) {
+            // the same lists from the device: counted, scanned, filled and sorted there (rtw_build_kernels.h); only the offsets come back (tile weights)
+            off.resize(n_bins + 1);
+            uint32_t *d_off = nullptr, *d_ent = nullptr; int has = 0;
+            const hipError_t be = (hipError_t)rtw::device_build_bins(scene->d_nodes_of[s], scene->d_tris_of[s], (int)scene->meshes[s]->nodes.size(), width, height, bin_w, bin_h,
+                                                                     &d_off, &d_ent, off.data(), &has, scene->ctx->stream);
+            if (be != hipSuccess) return hip_fail(be, "device bins build");
+            if (!has) { for (auto& w : weight) w += 1000u; continue; }
+            scene->allocs.push_back(d_off); scene->allocs.push_back(d_ent);
+            for (size_t b = 0; b < n_bins; b++) weight[b] += off[b + 1] - off[b];
+            h[s].off = d_off; h[s].ent = d_ent;
+            continue;
+        }
         if (!rtw::build_bins(*scene->meshes[s], width, height, bin_w, bin_h, off, ent)) { for (auto& w : weight) w += 1000u; continue; }
         for (size_t b = 0; b < n_bins; b++) weight[b] += off[b + 1] - off[b];
         int rc;
