@@ -81,7 +81,9 @@ int rtw_context_destroy(rtw_context* ctx);
 int rtw_context_set_stream(rtw_context* ctx, void* hip_stream);
 int rtw_context_synchronize(rtw_context* ctx);
 /* Tuning switches; results never depend on them (every combination is tested bit-identical).
- *   "pipeline"      3 (default) = screen bins for the camera rays (hits shaded in the same kernel, sky tiles in a
+ *   "pipeline"      4 (default) = pass-batched: the passes of one rtw_render_passes call are rendered in groups that share one set of launches (screen
+ *                   bins for the camera rays, a ray per lane for the bounce rounds; rtw_group_kernels.h), every frame shape, pixel range and scene;
+ *                   3 = screen bins for the camera rays (hits shaded in the same kernel, sky tiles in a
  *                   second kernel on a side stream) + one wave-per-ray trace launch and one shade launch per bounce;
  *                   2 = packet walk for camera rays + a 16-lanes-per-ray trace and a shade launch per bounce;
  *                   1 = packet walk + one path kernel + resolve; 0 = one kernel, one thread per pixel.
@@ -98,8 +100,12 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   "hint_period" (16) the queue lengths that size the next launches are read back every n-th pass.
  *   pipelines 1, 2: "packets" (1) camera rays traced as 64-ray packets inside the primary kernel; "path_lanes" lanes per
  *                   ray in the path kernel: 16 (default), 4 or 1; "path_variant": occupancy variants of the path kernel.
- *   "kernel_timing" 1 = record events around the stages of each pass (rtw_last_pass_kernel_ms);
- *   "debug_primary" timing experiments only (skips work: wrong images). */
+ *   "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms).
+ *   Pass-batched pipeline (4): "group_max" (64) passes per group at most (a power of two), "group_paths" (4 Mi) paths a launch should hold;
+ *                   "trace_stage" (1) the trace blocks stage the first mesh's upper tree levels in LDS; "trace_persist" (1) one-mesh scenes: persistent
+ *                   trace waves that refill their lanes; "wave_below" (160 000) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
+ *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (256) big trees: a ray's node visits in the
+ *                   ray-per-lane kernel before it goes to the wave-per-ray one; "device_build" (1) tree, layouts and screen bins built on the device. */
 int rtw_context_set_option(rtw_context* ctx, const char* name, int value);
 /* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's three stages -- primary kernel(s),
  * the per-bounce trace / shade launches, resolve -- measured on the context's stream; waits for that pass. */

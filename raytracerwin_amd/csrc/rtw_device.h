@@ -57,7 +57,7 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
 // device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)
 size_t pipeline_counters_offset(long long work_items, int max_bounce);
 // ---- pass-batched pipeline (pipeline 4, rtw_group_kernels.h) ----
-struct GroupLayout { size_t counters_off, rad_off, state_off, hit_off, carry_off, levels_off, list0_off, list1_off, overflow_off, total; };
+struct GroupLayout { size_t counters_off, rad_off, state_off, hit_off, carry_off, levels_off, list0_off, list1_off, overflow_off, tlist0_off, tlist1_off, total; };
 // device bytes of a group's workspace: `capacity` path slots (busy tiles x 64 x sub-samples x passes of the group, rounded up to a power of two of passes)
 size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupLayout* out);
 struct GroupTuning {
@@ -72,6 +72,8 @@ struct GroupTuning {
     int cu_count = 256;
     bool single_mesh = false, persist = true; // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
+    int trace_hint[32];                      // scenes with leading analytic shapes: how many rays of a round still went to the trace launch (previous group)
+    bool skip_trace = false;                 // every shape is a leading analytic shape: the shading lanes do the whole query, no trace launches
     int overflow_hint[32];                   // how many rays that were in the previous group, per round (-1 = unknown)
     int wide_below = 0; bool wide_ok = false;  // lists between wave_below and wide_below rays run sixteen lanes per ray on the 16-wide tree (all meshes have one)
     int wave_below = 0;                      // a trace round whose list (previous group's length) is shorter than this runs a wave per ray

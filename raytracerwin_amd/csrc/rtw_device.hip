@@ -2250,7 +2250,9 @@ size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupL
     l.list0_off = l.levels_off + up(cap * (size_t)(max_bounce > 0 ? max_bounce : 1) * 48);
     l.list1_off = l.list0_off + up(cap * 4);
     l.overflow_off = l.list1_off + up(cap * 4);
-    l.total = l.overflow_off + up(cap * 4);
+    l.tlist0_off = l.overflow_off + up(cap * 4);
+    l.tlist1_off = l.tlist0_off + up(cap * 4);
+    l.total = l.tlist1_off + up(cap * 4);
     if (out) *out = l;
     return l.total;
 }
@@ -2265,7 +2267,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     GroupBufs gb;
     gb.rad = (float4*)(w + l.rad_off); gb.state = (float4*)(w + l.state_off); gb.hit = (float4*)(w + l.hit_off);
     gb.carry = tune.carry ? (float4*)(w + l.carry_off) : nullptr; gb.levels = (float4*)(w + l.levels_off);
-    gb.list0 = (uint32_t*)(w + l.list0_off); gb.list1 = (uint32_t*)(w + l.list1_off); gb.overflow = (uint32_t*)(w + l.overflow_off); gb.counters = (uint32_t*)(w + l.counters_off);
+    gb.list0 = (uint32_t*)(w + l.list0_off); gb.list1 = (uint32_t*)(w + l.list1_off); gb.overflow = (uint32_t*)(w + l.overflow_off); gb.tlist0 = (uint32_t*)(w + l.tlist0_off); gb.tlist1 = (uint32_t*)(w + l.tlist1_off); gb.counters = (uint32_t*)(w + l.counters_off);
     gb.capacity = (uint32_t)tune.capacity; gb.carry_on = tune.carry ? 1 : 0;
     if (!tune.counters_clean) { hipError_t e = hipMemsetAsync(gb.counters, 0, 256, stream); if (e != hipSuccess) return (int)e; }
     bool forked = false;
@@ -2311,37 +2313,42 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
         };
         if (!p.preview) {
             for (int r = 1; r < p.max_bounce; r++) {       // the primary kernel was shade(0); trace(r - 1) then shade(r)
-                const unsigned tb = blocks_for(r - 1);
+                const unsigned sb_full = blocks_for(r - 1);  // the round's whole list (the shade launch)
+                // the rays the trace launch takes: the whole list, or (leading analytic shapes) the part the shading lanes could not finish
+                const int trace_hint = p.lead_shapes > 0 ? tune.trace_hint[r - 1] : tune.round_hint[r - 1];
+                unsigned tb = sb_full;
+                if (p.lead_shapes > 0 && trace_hint >= 0) { long long bl = ((long long)trace_hint + trace_hint / 4 + 1024 + 255) / 256; if (bl < (long long)tb) tb = (unsigned)(bl < 1 ? 1 : bl); }
+                if (!tune.skip_trace) {
 #define RTW_LAUNCH_GT(ST, AN_, NT_, CAP_, STG, BLOCKS, DYN)                                                                                      \
                 do {                                                                                                                            \
                     if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_kernel<ST, AN_, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                    hipLaunchKernelGGL((gtrace_kernel<ST, AN_, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.staged_shape); \
+                    hipLaunchKernelGGL((gtrace_kernel<ST, AN_, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.staged_shape, p.lead_shapes); \
                 } while (0)
 #define RTW_LAUNCH_GT4(NT_, CAP_, STG, BLOCKS, DYN)                                                                                             \
                 do {                                                                                                                            \
                     if (tune.has_analytic) { if (stats) RTW_LAUNCH_GT(true, true, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, true, NT_, CAP_, STG, BLOCKS, DYN); } \
                     else { if (stats) RTW_LAUNCH_GT(true, false, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, false, NT_, CAP_, STG, BLOCKS, DYN); } \
                 } while (0)
-                if (!tune.has_analytic && tune.wide_ok && tune.round_hint[r - 1] >= 0 && tune.round_hint[r - 1] < tune.wide_below && tune.round_hint[r - 1] >= tune.wave_below) {
+                if (!tune.has_analytic && tune.wide_ok && trace_hint >= 0 && trace_hint < tune.wide_below && trace_hint >= tune.wave_below) {
                     // a medium list: sixteen lanes per ray on the 16-wide tree
-                    long long blocks = ((long long)tune.round_hint[r - 1] + tune.round_hint[r - 1] / 4 + 256 + 15) / 16;
+                    long long blocks = ((long long)trace_hint + trace_hint / 4 + 256 + 15) / 16;
                     if (blocks > 262144) blocks = 262144;
                     if (stats) hipLaunchKernelGGL(gtrace_wide_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, sc, gb, r - 1);
                     else hipLaunchKernelGGL(gtrace_wide_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, sc, gb, r - 1);
-                } else if (!tune.carry && tune.round_hint[r - 1] >= 0 && tune.round_hint[r - 1] < tune.wave_below) {
+                } else if (!tune.carry && trace_hint >= 0 && trace_hint < tune.wave_below) {
                     // a short list: a wave per ray (128-thread blocks, a wave takes rays in turn)
                     constexpr int NTV = 128;
-                    long long blocks = ((long long)tune.round_hint[r - 1] + tune.round_hint[r - 1] / 4 + 64 + NTV / 64 - 1) / (NTV / 64);
+                    long long blocks = ((long long)trace_hint + trace_hint / 4 + 64 + NTV / 64 - 1) / (NTV / 64);
                     const long long cap = (long long)tune.cu_count * 64;
                     if (blocks < 1) blocks = 1;
                     if (blocks > cap) blocks = cap;
                     const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
                     if (tune.has_analytic) {
-                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
-                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
                     } else {
-                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
-                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0);
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
                     }
                 } else if (tune.single_mesh && tune.persist) {
                     // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
@@ -2374,8 +2381,8 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         const long long cap = (long long)tune.cu_count * 64;
                         if (blocks > cap) blocks = cap;
                         const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
-                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1);
-                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1);
+                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, 0);
+                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, 0);
                     }
                 } else if (tune.staged_shape >= 0 && tune.staged_top > 0) {
                     const unsigned sbl = (tb + 3) / 4;          // 1024-thread blocks
@@ -2388,12 +2395,13 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                 }
 #undef RTW_LAUNCH_GT4
 #undef RTW_LAUNCH_GT
+                }
                 if (tune.has_analytic) {
-                    if (stats) hipLaunchKernelGGL((gshade_kernel<true, true>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
-                    else hipLaunchKernelGGL((gshade_kernel<false, true>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
+                    if (stats) hipLaunchKernelGGL((gshade_kernel<true, true>), dim3(sb_full), dim3(256), 0, stream, sc, gb, g, r);
+                    else hipLaunchKernelGGL((gshade_kernel<false, true>), dim3(sb_full), dim3(256), 0, stream, sc, gb, g, r);
                 } else {
-                    if (stats) hipLaunchKernelGGL((gshade_kernel<true, false>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
-                    else hipLaunchKernelGGL((gshade_kernel<false, false>), dim3(tb), dim3(256), 0, stream, sc, gb, g, r);
+                    if (stats) hipLaunchKernelGGL((gshade_kernel<true, false>), dim3(sb_full), dim3(256), 0, stream, sc, gb, g, r);
+                    else hipLaunchKernelGGL((gshade_kernel<false, false>), dim3(sb_full), dim3(256), 0, stream, sc, gb, g, r);
                 }
             }
         }

@@ -38,6 +38,8 @@ struct GroupBufs {
     float4* __restrict__ levels;    // [capacity * max_bounce * 3]
     uint32_t* __restrict__ list0;   // ray lists (slots), ping-pong
     uint32_t* __restrict__ list1;
+    uint32_t* __restrict__ tlist0;  // scenes whose first shapes are analytic (rp.lead_shapes > 0): the subset of a round's list whose query is not finished
+    uint32_t* __restrict__ tlist1;  // by the lane that set the segment up -- the trace kernels take these; lengths: counters[24 + round]
     uint32_t* __restrict__ overflow;// rays the budgeted ray-per-lane walk handed over to the wave-per-ray kernel; its length: counters[40 + round]
     uint32_t* __restrict__ counters;// [r] = length of round r's list; [64 + r] = the same at the end of the previous group (for the host)
     uint32_t capacity;
@@ -126,6 +128,35 @@ __device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__
     return false;
 }
 
+// A scene whose first `lead` shapes are spheres / planes / capsules / triangles (the reference's default scene: six of them before the mesh): the
+// lane that sets a segment up runs FindIntersectionWithScene's first `lead` iterations itself, a ray per lane (Src/RayTracerScene.cpp:99-125:
+// the same tests in the same order on the same running distance), and gives the boxes of the shapes after them the reference's own culling test
+// (plus, for meshes, the walk's conservative segment clip).  A ray that meets none of those boxes has its complete result already and never
+// enters a trace kernel; the others continue there from this record.  Returns true when the query must go on.
+template <bool STATS>
+__device__ __forceinline__ bool group_lead_query(const RtwSceneDev* __restrict__ sc, int lead, const Ray& ray, float4& r0, float4& r1, Counters& ct)
+{
+    int hs = -1, hslot = -1; f3 hp = mk(0, 0, 0); float seg = ray.dist;
+    lead_find<STATS>(sc, lead, ray, seg, hs, hslot, hp, ct);
+    const int n_shapes = sc->n_shapes;
+    bool more = false; uint32_t tested = 0u;
+    const bool cull = sc->prune != 0 && ray_is_tame(ray);
+    const float eps_t = 2.0e-5f * fmaxf(fabsf(1.0f / ray.d.x), fmaxf(fabsf(1.0f / ray.d.y), fabsf(1.0f / ray.d.z)));
+    for (int s = lead; s < n_shapes; s++) {
+        const RtwShapeDev& sh = sc->shapes[s];
+        float t0, t1;
+        if (sh.kind == RTW_SHAPE_PLANE) { more = true; continue; }
+        tested++;
+        if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
+        if (cull && sh.kind == RTW_SHAPE_MESH && (t0 > seg + (eps_t + 1.0e-4f * seg) || t1 < -eps_t)) continue;     // (meshes only: their walk applies the same clip)
+        more = true;
+    }
+    if (STATS && !more) { ct.rays++; ct.boxes += tested; }       // (a ray that goes on is counted by the trace kernel)
+    r0 = make_float4(hp.x, hp.y, hp.z, seg);
+    r1 = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(-1), __int_as_float(-1));
+    return more;
+}
+
 __device__ __forceinline__ void group_save_state(const GroupBufs& gb, uint32_t slot, const Ray& ray, const PathRng& rng, int depth, int nlev, int pixel)
 {
     gb.state[(size_t)slot * 3] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
@@ -209,7 +240,7 @@ __global__ __launch_bounds__(256) void gprimary_kernel(const RtwSceneDev* __rest
             const uint32_t* __restrict__ boff = p.bins[k].off;
             near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);
         }
-        uint32_t queued = 0u;
+        uint32_t queued = 0u, tqueued = 0u;
         for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
             if (only_sample >= 0 && i != only_sample) continue;
             PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass, (uint32_t)i);
@@ -321,6 +352,11 @@ __global__ __launch_bounds__(256) void gprimary_kernel(const RtwSceneDev* __rest
                 if (group_shade_step<STATS, AN>(sc, p, gb, slot, r, rg, depth, nlev, hr0, hr1, hr2, L, ct)) {
                     group_save_state(gb, slot, r, rg, depth, nlev, pixel);
                     queued |= 1u << i;
+                    if (AN && p.lead_shapes > 0) {
+                        float4 q0, q1;
+                        if (group_lead_query<STATS>(sc, p.lead_shapes, r, q0, q1, ct)) tqueued |= 1u << i;
+                        gb.hit[(size_t)slot * 2] = q0; gb.hit[(size_t)slot * 2 + 1] = q1;
+                    }
                 } else {
                     si = mk(0, 0, 0) + L;
                     gb.rad[slot] = make_float4(si.x, si.y, si.z, 0.0f);
@@ -341,6 +377,10 @@ __global__ __launch_bounds__(256) void gprimary_kernel(const RtwSceneDev* __rest
             if (queued & 2u) gb.list0[qb + c0 + (uint32_t)mbcnt(m1)] = group_slot(g, b, (uint32_t)lane, 1u, kpass);
             if (queued & 4u) gb.list0[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = group_slot(g, b, (uint32_t)lane, 2u, kpass);
             if (queued & 8u) gb.list0[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = group_slot(g, b, (uint32_t)lane, 3u, kpass);
+        }
+        if (AN && p.lead_shapes > 0) {       // the subset that still has to be traced
+            for (uint32_t i = 0; i < (uint32_t)p.sub_samples; i++)
+                wave_push(gb.tlist0, &gb.counters[24], (tqueued >> i) & 1u, group_slot(g, b, (uint32_t)lane, i, kpass));
         }
     }
     if (STATS) flush_counters(sc, ct);
@@ -472,7 +512,7 @@ __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* 
 // staged_shape: the shape whose upper tree levels the block holds in LDS (lnodes, ltop), or -1
 template <bool STATS, bool AN, int NT, int CAP, bool ALLDS>
 __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ cand, const float4* __restrict__ lnodes, int ltop, int staged_shape,
-                                                       const Ray& ray, bool have,
+                                                       const Ray& ray, bool have, int first_shape,
                                                        int& hit_shape, int& hit_slot, f3& hit_pos, float& seg,
                                                        int& carry_shape, int& carry_slot, f3& carry_pos, float& carry_dist, Counters& ct,
                                                        int& dbg_walk, int& dbg_tri, int& dbg_flush)
@@ -481,7 +521,7 @@ __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __rest
     const bool prune = sc->prune != 0;
     const LaneRay q = lane_ray_of(ray);
     if (STATS && have) ct.rays++;
-    for (int s = 0; s < n_shapes; s++) {
+    for (int s = first_shape; s < n_shapes; s++) {
         const RtwShapeDev& sh = sc->shapes[s];
         const int kind = AN ? sh.kind : RTW_SHAPE_MESH;
         float t0, t1;
@@ -510,11 +550,13 @@ __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __rest
 // one dependent node fetch, ~100 ns from LDS against ~600 ns through L2.
 // STAGE 0: nothing staged; 1: the upper levels (the walk goes on in global memory below them); 2: the whole tree fits (ALLDS)
 template <bool STATS, bool AN, int NT, int CAP, int STAGE>
-__global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int staged_shape)
+__global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int staged_shape, int lead)
 {
     extern __shared__ uint32_t gt_dyn[];                 // [CAP * NT candidate words | staged records]
     uint32_t* cand = gt_dyn;
-    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
+    // lead > 0: the scene's first `lead` shapes were tested by the lane that set the segment up; the list holds the rays that go on, their records the state so far
+    const uint32_t nl = lead > 0 ? gb.counters[24 + round] : gb.counters[round];
+    const uint32_t n = nl < gb.capacity ? nl : gb.capacity;
     if ((uint32_t)blockIdx.x * (uint32_t)NT >= n) return;        // (whole block) the grid is sized from the previous group's list length
     const float4* lnodes = nullptr; int ltop = 0;
     if (STAGE) {
@@ -526,7 +568,7 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
         lnodes = dst;
         __syncthreads();
     }
-    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
+    const uint32_t* __restrict__ src = lead > 0 ? (round & 1 ? gb.tlist1 : gb.tlist0) : (round & 1 ? gb.list1 : gb.list0);
     const uint32_t nthreads = gridDim.x * (uint32_t)NT;
     const uint32_t lane = (uint32_t)lane_id();
     Counters ct = { 0, 0, 0, 0, 0, 0 };
@@ -545,10 +587,14 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
             ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         }
         int hs = -1, hslot = -1, cs = -1, cslot = -1; f3 pos = mk(0, 0, 0), cpos = mk(0, 0, 0); float seg = ray.dist, cdist = 0.0f;
+        if (AN && lead > 0 && have) {        // continue the query from what the shading lane found among the leading shapes
+            const float4 h0 = gb.hit[(size_t)slot * 2], h1 = gb.hit[(size_t)slot * 2 + 1];
+            pos = mk(h0.x, h0.y, h0.z); seg = h0.w; hs = __float_as_int(h1.x); hslot = __float_as_int(h1.y);
+        }
 #ifdef RTW_TIMING
         rtw_t1 = wall_clock64();
 #endif
-        lane_find_intersection<STATS, AN, NT, CAP, (STAGE == 2)>(sc, cand, lnodes, ltop, STAGE ? staged_shape : -1, ray, have, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct,
+        lane_find_intersection<STATS, AN, NT, CAP, (STAGE == 2)>(sc, cand, lnodes, ltop, STAGE ? staged_shape : -1, ray, have, AN ? lead : 0, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct,
                                                                  dbg_walk, dbg_tri, dbg_flush);
         if (have) {
             gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, seg);
@@ -791,15 +837,15 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
 // handful of dependent steps wins (the host picks by the previous group's list length).  Not for texel-inheritance scenes.
 // from_overflow: the list is the one the budgeted ray-per-lane kernel of this round filled.
 template <bool STATS, bool AN, int NT>
-__global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int from_overflow)
+__global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int from_overflow, int lead)
 {
     extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
-    const uint32_t nl = from_overflow ? gb.counters[40 + round] : gb.counters[round];
+    const uint32_t nl = from_overflow ? gb.counters[40 + round] : (lead > 0 ? gb.counters[24 + round] : gb.counters[round]);
     const uint32_t n = nl < gb.capacity ? nl : gb.capacity;
     if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;
     uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
     const FlatSrc shape0 = flat_src_of(sc->shapes[0]);
-    const uint32_t* __restrict__ src = from_overflow ? gb.overflow : (round & 1 ? gb.list1 : gb.list0);
+    const uint32_t* __restrict__ src = from_overflow ? gb.overflow : (lead > 0 ? (round & 1 ? gb.tlist1 : gb.tlist0) : (round & 1 ? gb.list1 : gb.list0));
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
     const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);
@@ -810,7 +856,11 @@ __global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __re
         const float4 s0 = cld4(gb.state, q * 3), s1 = cld4(gb.state, q * 3 + 1);
         Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
-        wave_find_intersection<STATS, 0, AN>(sc, 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
+        if (AN && lead > 0) {
+            const float4 h0 = cld4(gb.hit, q * 2), h1 = cld4(gb.hit, q * 2 + 1);
+            pos = mk(h0.x, h0.y, h0.z); seg = h0.w; hs = __float_as_int(h1.x); slot = __float_as_int(h1.y);
+        }
+        wave_find_intersection<STATS, 0, AN>(sc, AN ? lead : 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
         if (lane_id() == 0) {
             gb.hit[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             gb.hit[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), __int_as_float(-1), __int_as_float(-1));
@@ -887,7 +937,7 @@ __global__ __launch_bounds__(256, 3) void gshade_kernel(const RtwSceneDev* __res
     for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < trips; it++, k += nthreads) {
         const bool live = k < n;
         const uint32_t slot = live ? src[k] : 0u;
-        bool go_on = false;
+        bool go_on = false, trace_on = false;
         if (live && slot < gb.capacity) {
             const float4 s0 = gb.state[(size_t)slot * 3], s1 = gb.state[(size_t)slot * 3 + 1], s2 = gb.state[(size_t)slot * 3 + 2];
             Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
@@ -907,10 +957,17 @@ __global__ __launch_bounds__(256, 3) void gshade_kernel(const RtwSceneDev* __res
             if (AN && gb.carry_on) r2 = gb.carry[slot];
             f3 L;
             go_on = group_shade_step<STATS, AN>(sc, p, gb, slot, ray, rng, depth, nlev, r0, r1, r2, L, ct);
-            if (go_on) group_save_state(gb, slot, ray, rng, depth, nlev, pixel);
-            else { const f3 c = mk(0, 0, 0) + L; gb.rad[slot] = make_float4(c.x, c.y, c.z, 0.0f); }
+            if (go_on) {
+                group_save_state(gb, slot, ray, rng, depth, nlev, pixel);
+                if (AN && p.lead_shapes > 0) {
+                    float4 q0, q1;
+                    trace_on = group_lead_query<STATS>(sc, p.lead_shapes, ray, q0, q1, ct);
+                    gb.hit[(size_t)slot * 2] = q0; gb.hit[(size_t)slot * 2 + 1] = q1;
+                }
+            } else { const f3 c = mk(0, 0, 0) + L; gb.rad[slot] = make_float4(c.x, c.y, c.z, 0.0f); }
         }
         wave_push(dst, &gb.counters[round], go_on, slot);
+        if (AN && p.lead_shapes > 0) wave_push(round & 1 ? gb.tlist1 : gb.tlist0, &gb.counters[24 + round], trace_on, slot);
     }
     if (STATS) flush_counters(sc, ct);
 }

@@ -136,6 +136,7 @@ struct rtw_context {
     int last_group_passes = 0;          // passes of the latest group (rtw_last_group_passes)
     int known_ground[32];
     int known_goverflow[24];
+    int known_gtrace[16];
     int visit_budget = 256;             // one-mesh scenes with a big tree: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
     int group_paths = 4 << 20;          // passes are grouped until a launch holds about this many paths ...
     int group_max = 64;                 // ... and at most this many passes (a power of two)
@@ -249,6 +250,7 @@ int rtw_context_create(int device_index, rtw_context** out)
     for (int i = 0; i < 64; i++) c->h_gcounters[i] = 0;
     for (int r = 0; r < 32; r++) c->known_ground[r] = -1;
     for (int r = 0; r < 24; r++) c->known_goverflow[r] = -1;
+    for (int r = 0; r < 16; r++) c->known_gtrace[r] = -1;
     for (int i = 0; i < 64; i++) c->h_counters[i] = 0;
     for (int r = 0; r < 32; r++) c->known_rounds[r] = -1;
     HIP_TRY(hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)));
@@ -317,7 +319,9 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         ctx->wave_stage = value;
         return RTW_OK;
     }
+#ifdef RTW_DEBUG_OPTIONS        // timing experiments that skip work (wrong images): not in the release library
     if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
+#endif
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "auto_fused") == 0) { ctx->auto_fused = value ? 1 : 0; return RTW_OK; }
@@ -606,7 +610,9 @@ int rtw_scene_commit(rtw_scene* scene)
     h->n_shapes = (int)scene->meshes.size();
     h->prune = scene->prune;
     h->traversal = scene->traversal;
+#ifdef RTW_DEBUG_OPTIONS
     if (const char* dm = std::getenv("RTW_DEBUG_TABLE_MASK")) h->debug_table_mask = (int32_t)std::strtol(dm, nullptr, 0);
+#endif
     h->unit_table = scene->ctx->d_unit;
     h->gamma_thr = scene->ctx->d_gamma;
     h->texel_lut = scene->ctx->d_lut;
@@ -1220,6 +1226,11 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
         g.n_busy = gt->n_busy; g.n_sky = gt->n_sky; g.n_jobs = gt->n_jobs;
         g.busy_tiles = gt->d_busy; g.sky_tiles = gt->d_sky; g.jobs = gt->d_jobs;
     }
+    {   // the scene's leading spheres / planes / capsules / triangles are tested by the lane that sets a segment up (group_lead_query)
+        int lead = 0;
+        while (lead < (int)scene->meshes.size() && scene->meshes[(size_t)lead]->kind != RTW_SHAPE_MESH) lead++;
+        p.lead_shapes = cx->lead_split ? lead : 0;
+    }
     g.rp = p;
     const bool carry = scene->texture_carry;
     const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
@@ -1262,12 +1273,15 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
         cx->known_gkey = cx->gcounters_key; cx->gcounters_pending = false;
         const int np = cx->gcounters_passes > 0 ? cx->gcounters_passes : 1;
         for (int r = 0; r < 32; r++) cx->known_ground[r] = (int)((cx->h_gcounters[r] + (uint32_t)np - 1u) / (uint32_t)np);          // per pass, rounded up
-        for (int r = 0; r < 24; r++) cx->known_goverflow[r] = (int)((cx->h_gcounters[40 + r] + (uint32_t)np - 1u) / (uint32_t)np);
+        for (int r = 0; r < 16; r++) cx->known_goverflow[r] = (int)((cx->h_gcounters[40 + r] + (uint32_t)np - 1u) / (uint32_t)np);
+        for (int r = 0; r < 16; r++) cx->known_gtrace[r] = (int)((cx->h_gcounters[24 + r] + (uint32_t)np - 1u) / (uint32_t)np);
     }
     auto scaled = [&](int per_pass) { const long long v = (long long)per_pass * n_passes; return (int)(v > INT32_MAX ? INT32_MAX : v); };
     for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_ground[r]) : -1;
-    for (int r = 0; r < 24; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_goverflow[r]) : -1;
-    for (int r = 24; r < 32; r++) tune.overflow_hint[r] = -1;
+    for (int r = 0; r < 32; r++) { tune.overflow_hint[r] = -1; tune.trace_hint[r] = -1; }
+    for (int r = 0; r < 16; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_goverflow[r]) : -1;
+    for (int r = 0; r < 16; r++) tune.trace_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_gtrace[r]) : -1;
+    tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();
     cx->group_clean = false;
     const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws, g, tune, cx->stats_enabled, cx->stream);
     if (e != hipSuccess) return hip_fail(e, "group launch");

@@ -286,3 +286,18 @@ def test_analytic_shapes_keep_insertion_order_and_the_reference_culling_boxes(or
     assert len(SC.default_scene()) == 7
     with pytest.raises(R.RtwError):
         s.AddShape(R.RSphere.Create((0, 0, 0), 1.0))        # committed
+
+
+def test_device_code_under_address_and_ub_sanitizers(tmp_path):
+    """tests/cpu_emul compiles rtw_device.hip for the HOST (RTW_HOST_EMUL) with -fsanitize=address,undefined and runs the one-thread-per-pixel
+    kernel -- the ray / box / triangle / texture / material / path code every pipeline shares -- over small frames of a plain and a textured mesh
+    (GPU sanitizers are not available on the pool).  Any out-of-bounds access or undefined operation aborts the run."""
+    import subprocess
+    here = os.path.join(ROOT, "tests", "cpu_emul")
+    subprocess.check_call(["make", "-C", here], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    exe = os.path.join(here, "_build", "emul_main")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    for args in (["TorusKnot.obj", "96", "54", "2", "4"], ["unitychan.obj", "64", "64", "1", "3"], ["BlenderMonkey.obj", "48", "48", "4", "2", "0", "48", "0", "0"]):
+        r = subprocess.run([exe, asset(args[0])] + args[1:], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "emul ok" in r.stdout, r.stderr[-2000:]
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
