@@ -232,7 +232,8 @@ def main():
     ap.add_argument("--option", action="append", default=[], help="name=value context option (experiments)")
     ap.add_argument("--depth", type=int, default=0, help="override the config's depth (experiments only)")
     ap.add_argument("--gather", default="native", choices=("native", "torch"), help="N>1: rtw_gather_rows (RCCL send/recv out of the framebuffers) or torch.distributed.gather")
-    ap.add_argument("--argb-only", action="store_true", help="N>1: gather the displayable image only (4 B/pixel)")
+    ap.add_argument("--gather-accum", action="store_true", help="N>1: gather the float accumulator (16 B/pixel) as well as the ARGB image (4 B/pixel); the default moves what "
+                                                              "the reference writes out after its passes, the image")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -316,9 +317,9 @@ def main():
 
     def gather():
         if comm is not None:
-            comm.gather_rows(fb, TASK_ROWS, args.argb_only)
+            comm.gather_rows(fb, TASK_ROWS, (not args.gather_accum))
         else:
-            bufs = [argb.view(H, W)] if args.argb_only else [accum.view(H, W * 4), argb.view(H, W)]
+            bufs = [argb.view(H, W)] if (not args.gather_accum) else [accum.view(H, W * 4), argb.view(H, W)]
             sharding.gather_rows(bufs, H, TASK_ROWS, rank, world, dist, dev)
 
     def barrier():
@@ -379,7 +380,7 @@ def main():
         b2 = fb2.resolve_argb()
         ctx.set_option("pipeline", args.pipeline)
         same_argb = bool((b2 == final_argb).all())
-        same_accum = bool((a2.view(np.uint32) == final_accum).all()) if not (world > 1 and args.argb_only) else None
+        same_accum = bool((a2.view(np.uint32) == final_accum).all()) if not (world > 1 and (not args.gather_accum)) else None
         verified = bool(same_argb and same_accum is not False)
         # ---- work counters of the K timed passes as the timed pipeline runs them (one GPU, same grouping)
         ctx.stats_enable(True)
@@ -495,7 +496,7 @@ def main():
         }
         if world > 1:
             result["gather_ms"] = gather_ms
-            result["gather"] = gather_kind + ("; ARGB only" if args.argb_only else "; accumulator + ARGB")
+            result["gather"] = gather_kind + ("; ARGB only" if (not args.gather_accum) else "; accumulator + ARGB")
             result["gather_verified_bit_identical_to_1gpu"] = verified
         if world == 1 and not args.no_cpu:
             try:

@@ -830,3 +830,22 @@ def test_device_built_trees_of_awkward_meshes_render_like_host_built_ones(ctx):
         ctx.set_option("device_build", 1)
         for x, y in zip(res[1], res[0]):
             assert (bits(x) == bits(y)).all() if x.dtype == np.float32 else (x == y).all(), (n, kind)
+
+
+@pytest.mark.gpu
+def test_native_gather_communicator_on_one_rank(ctx):
+    """rtw_comm_create / rtw_gather_rows / rtw_comm_destroy with a world of one: librccl is found (the copy already in the process when PyTorch is
+    loaded, else ROCm's), ncclCommInitRank succeeds on this GPU, and the gather of a one-rank world moves nothing and changes nothing.  (The
+    exchange between ranks needs several GPUs: bench.py --gpus N checks it against a one-GPU replay.)"""
+    import torch  # noqa: F401  (so that PyTorch's librccl is the one in the process, as in bench.py)
+    s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Diffuse())
+    fb = R.Framebuffer(ctx, 320, 180)
+    s.render_passes(fb, 10, 0, 1, 3, None, 0, 2, 2, 5)
+    before = (fb.read_float(), fb.resolve_argb())
+    comm = R.Comm(ctx, 0, 1)
+    comm.gather_rows(fb, 10)
+    comm.gather_rows(fb, 10, argb_only=True)
+    ctx.synchronize()
+    after = (fb.read_float(), fb.resolve_argb())
+    comm.close()
+    assert (bits(before[0]) == bits(after[0])).all() and (before[1] == after[1]).all()
