@@ -297,16 +297,31 @@ def main():
     comm = None
     gather_kind = None
     if world > 1 and args.gather == "native":
-        def bootstrap(ident):       # rank 0's ncclUniqueId to every rank, through the process group the launcher set up
-            t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
-            dist.broadcast(t, src=0)
-            return bytes(t.cpu().tolist())
-        try:
-            comm = R.Comm(ctx, rank, world, bootstrap)
+        # rank 0's ncclUniqueId to every rank through the process group the launcher set up; every rank takes the same decision at every step, so
+        # that a failure on one of them (librccl not loadable, communicator not created) sends ALL ranks to the torch.distributed gather together
+        note = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                note[1:] = torch.tensor(list(R.Comm.unique_id()), dtype=torch.uint8, device=dev)
+                note[0] = 1
+            except Exception:
+                note[0] = 0
+        dist.broadcast(note, src=0)
+        made = torch.zeros(1, dtype=torch.int32, device=dev)
+        if int(note[0].item()) == 1:
+            try:
+                comm = R.Comm(ctx, rank, world, bytes(note[1:].cpu().tolist()))
+                made[0] = 1
+            except Exception:
+                comm = None
+        dist.all_reduce(made, op=dist.ReduceOp.MIN)
+        if int(made.item()) == 1:
             gather_kind = "rtw_gather_rows: grouped ncclSend / ncclRecv of every rank's task rows straight out of the framebuffers (RCCL over xGMI)"
-        except Exception as e:      # a broken RCCL bootstrap must not lose the measurement: the torch gather does the same exchange
+        else:
+            if comm is not None:
+                comm.close()
             comm = None
-            gather_kind = "torch.distributed.gather (rtw_comm_create failed: %r)" % (e,)
+            gather_kind = "torch.distributed.gather with staging copies (the native communicator could not be created on every rank)"
     elif world > 1:
         gather_kind = "torch.distributed.gather with staging copies"
 

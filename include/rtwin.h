@@ -230,7 +230,8 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
  * into a full-size framebuffer; rtw_gather_rows then moves every rank's rows to rank 0 over RCCL (xGMI): grouped ncclSend / ncclRecv
  * straight out of / into the framebuffers' device memory, on the context's stream, no staging copies.  No reference counterpart (the
  * reference is one process); it completes what UpdateBitmapPixels' WaitForAllTasksDone (Src/RayTracerProgram.cpp:303) is to one process.
- * librccl is loaded on first use (dlopen: the copy already in the process, e.g. PyTorch's, else librccl.so.1); single-GPU users never load it. ---- */
+ * librccl is loaded on first use (dlopen: the library the environment variable RTW_RCCL_LIBRARY names if it is set, else the copy already in the
+ * process, e.g. PyTorch's, else librccl.so.1); single-GPU users never load it. ---- */
 typedef struct rtw_comm rtw_comm;
 #define RTW_COMM_ID_BYTES 128
 /* rank 0: a fresh ncclUniqueId, to be handed to every rank by the caller (MPI, torch.distributed, a file ...) */

@@ -310,20 +310,26 @@ class Context:
 
 
 class Comm:
-    """rtw_comm: an RCCL communicator for the one exchange of the path (rtw_gather_rows).  `bootstrap` hands rank 0's 128-byte id to every
-    rank: a callable bytes -> bytes (e.g. a torch.distributed / MPI broadcast); with world == 1 nothing is exchanged."""
+    """rtw_comm: an RCCL communicator for the one exchange of the path (rtw_gather_rows).  Rank 0 makes an id with Comm.unique_id() and hands its
+    128 bytes to every rank (torch.distributed, MPI, a file ...); every rank then constructs Comm(ctx, rank, world, ident).  With world == 1 no
+    id is needed."""
 
-    def __init__(self, ctx, rank, world, bootstrap=None):
+    @staticmethod
+    def unique_id():
+        ident = (C.c_uint8 * 128)()
+        _check(library().rtw_comm_unique_id(ident))
+        return bytes(ident)
+
+    def __init__(self, ctx, rank, world, ident=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         self.h = C.c_void_p()
+        if ident is None:
+            if self.world != 1:
+                raise ValueError("Comm: every rank of a world > 1 needs rank 0's id")
+            ident = Comm.unique_id()
+        raw = (C.c_uint8 * 128).from_buffer_copy(bytes(ident))
+        _check(library().rtw_comm_create(ctx.h, raw, self.rank, self.world, C.byref(self.h)))
         ctx._children.add(self)
-        ident = (C.c_uint8 * 128)()
-        if self.rank == 0:
-            _check(library().rtw_comm_unique_id(ident))
-        if self.world > 1:
-            raw = bootstrap(bytes(ident))
-            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
-        _check(library().rtw_comm_create(ctx.h, ident, self.rank, self.world, C.byref(self.h)))
 
     def gather_rows(self, fb, task_rows, argb_only=False):
         _check(library().rtw_gather_rows(self.h, fb.h, int(task_rows), 1 if argb_only else 0))

@@ -1614,6 +1614,10 @@ const RcclApi* rccl_api()
     // the copy the process already holds (PyTorch ships its own librccl.so), else the ROCm one
     const char* names[] = { "librccl.so.1", "librccl.so" };
     void* h = nullptr;
+    if (const char* named = std::getenv("RTW_RCCL_LIBRARY")) {      // a deployment's own RCCL build (include/rtwin.h)
+        h = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { g_rccl.error = std::string("RTW_RCCL_LIBRARY: ") + (dlerror() ? dlerror() : "cannot load"); return nullptr; }
+    }
     for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);

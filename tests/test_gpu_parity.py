@@ -842,6 +842,7 @@ def test_native_gather_communicator_on_one_rank(ctx):
     fb = R.Framebuffer(ctx, 320, 180)
     s.render_passes(fb, 10, 0, 1, 3, None, 0, 2, 2, 5)
     before = (fb.read_float(), fb.resolve_argb())
+    assert len(R.Comm.unique_id()) == 128
     comm = R.Comm(ctx, 0, 1)
     comm.gather_rows(fb, 10)
     comm.gather_rows(fb, 10, argb_only=True)
@@ -849,3 +850,43 @@ def test_native_gather_communicator_on_one_rank(ctx):
     after = (fb.read_float(), fb.resolve_argb())
     comm.close()
     assert (bits(before[0]) == bits(after[0])).all() and (before[1] == after[1]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, "all"), (3, "argb")])
+def test_gather_plan_between_ranks_sharing_one_gpu(ctx, tmp_path, world, mode):
+    """rtw_gather_rows between real processes.  RCCL refuses two ranks on one GPU, so on this one-GPU box the transport underneath is the loopback
+    stand-in of tests/support/loopback_rccl.cpp (named pipes + host copies, loaded through RTW_RCCL_LIBRARY); everything above it is the product:
+    each rank renders its own 10-row tasks (the last task is ragged), the plan of rtw_gather_rows picks rows, offsets, peers and order, and
+    rank 0 must end up holding, bit for bit, the frame one rank renders alone (accumulators too in mode "all"; in mode "argb" the accumulator
+    rows of the other ranks stay zero on rank 0).  RCCL's own part is checked by bench.py --gpus N (gather_verified_bit_identical_to_1gpu)."""
+    import subprocess
+    import sys
+    sup = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support")
+    lib = str(tmp_path / "libloopback_rccl.so")
+    subprocess.run(["g++", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(sup, "loopback_rccl.cpp"),
+                    "-o", lib, "-L/opt/rocm/lib", "-lamdhip64"], check=True)
+    env = dict(os.environ, RTW_RCCL_LIBRARY=lib, RTW_LOOPBACK_DIR=str(tmp_path))
+    out = str(tmp_path / "rank0.npz")
+    procs = [subprocess.Popen([sys.executable, os.path.join(sup, "gather_rank.py"), str(r), str(world), mode, out], env=env) for r in range(world)]
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=180))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(-9)
+    assert codes == [0] * world
+    got = np.load(out)
+    W, H, ROWS = 200, 117, 10
+    s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Reflective())
+    fb = R.Framebuffer(ctx, W, H)
+    s.render_passes(fb, ROWS, 0, 1, 3, None, 0, 3, 2, 9)
+    want_accum, want_argb = fb.read_float(), fb.resolve_argb()
+    assert (got["argb"] == want_argb).all()
+    if mode == "all":
+        assert (bits(got["accum"]) == bits(want_accum)).all()
+    else:
+        row_task = (np.arange(W * H) // W) // ROWS
+        mine = (row_task % world) == 0
+        assert (bits(got["accum"][mine]) == bits(want_accum[mine])).all() and (got["accum"][~mine] == 0).all()
