@@ -8,7 +8,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.environ.get("RTW_LIB") or os.path.join(_HERE, "librtwin.so")      # RTW_LIB: an instrumented build (timing experiments)
+_LIB = os.environ.get("RTW_LIB") or os.path.join(_HERE, "librtwin.so")      # RTW_LIB: another BUILD of the same sources (timing instrumentation; the sanitizer build of tests/cpu_emul) -- never a fallback: unset, it is librtwin.so or an ImportError
 
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("r", "<f4"), ("g", "<f4"), ("b", "<f4"), ("param", "<f4"),
                            ("child_a", "<i4"), ("child_b", "<i4"), ("pad", "<i4")])

@@ -4,11 +4,7 @@
 // every float expression below keeps the operand order of the reference so that the GPU
 // result is bit-identical to the CPU oracle.  No MFMA: there is no dense contraction on
 // this path; the hot loop is a stack-free walk over 32-byte nodes (one ray per lane).
-#ifdef RTW_HOST_EMUL      // tests/cpu_emul: the same source compiled for the host, for sanitizer runs only
-#include "rtw_host_emul.h"
-#else
 #include <hip/hip_runtime.h>
-#endif
 #include <float.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -18,11 +14,7 @@
 #include <cstring>
 
 #include "rtw_types.h"
-#ifndef RTW_HOST_EMUL
 #include "rtw_device.h"
-#else
-#define RTW_MAX_BOUNCE_DEV 16
-#endif
 
 #ifdef RTW_TIMING
 __device__ unsigned long long g_rtw_timing[6 * 16384];
@@ -101,7 +93,7 @@ struct Counters { uint32_t rays, boxes, tris, hits, tex, cams; };
 // Loads/stores with an explicit address space.  Pointers that come out of the scene descriptor or out of a
 // struct are "generic" to the compiler, which then emits flat_* instructions (slower, and they tie the LDS
 // and vector-memory counters together); these helpers give it global_load_dwordx4 / ds_read_* instead.
-#if !defined(RTW_HOST_EMUL) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) const float4 rtw_g_f4;
 typedef __attribute__((address_space(1))) const float rtw_g_f1;
 typedef __attribute__((address_space(3))) const float rtw_l_f1;
@@ -173,16 +165,10 @@ __device__ __forceinline__ bool slab_exact(const Ray& r, float mnx, float mny, f
 // A ray is "tame" when every direction component is a normal number of magnitude >= FLT_EPSILON
 // and the origin is finite and moderate: then no slab axis is skipped and no NaN/inf can appear,
 // so Math::Min/Max equal v_min/v_max and the reciprocal can be hoisted out of the node loop.
-#ifdef RTW_HOST_EMUL
-static unsigned long long g_emul_tame = 0, g_emul_untame = 0;
-#endif
 __device__ __forceinline__ bool ray_is_tame_impl(const Ray& r);
 __device__ __forceinline__ bool ray_is_tame(const Ray& r)
 {
     const bool t = ray_is_tame_impl(r);
-#ifdef RTW_HOST_EMUL
-    if (t) g_emul_tame++; else { g_emul_untame++; if (g_emul_untame < 6) fprintf(stderr, "untame ray o=(%g %g %g) d=(%g %g %g)\n", r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z); }
-#endif
     return t;
 }
 __device__ __forceinline__ bool ray_is_tame_impl(const Ray& r)
@@ -289,11 +275,7 @@ __device__ __forceinline__ bool packet_walk(const RtwNode* nodes, const RtwTri* 
     bool any = false;
     int i = 0;
     while (i < n_nodes) {
-#ifndef RTW_HOST_EMUL
         const int iu = __builtin_amdgcn_readfirstlane(i);
-#else
-        const int iu = i;
-#endif
         const float4 lo = cld4(nd4, 2 * iu), hi = cld4(nd4, 2 * iu + 1);
         const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
         const float x1 = (lo.x - r.o.x) * ix, x2 = (hi.x - r.o.x) * ix;
@@ -312,11 +294,7 @@ __device__ __forceinline__ bool packet_walk(const RtwNode* nodes, const RtwTri* 
         bool hit = active && (tmax > tmin);
         if (!EXACT && prune) hit = hit && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
         if (STATS) ct.boxes += active ? 1u : 0u;
-#ifndef RTW_HOST_EMUL
         const bool any_hit = __ballot(hit) != 0ull;
-#else
-        const bool any_hit = hit;
-#endif
         if (leaf >= 0) {
             if (any_hit) {
                 const float4 a = cld4(tr4, 4 * leaf), b = cld4(tr4, 4 * leaf + 1), c = cld4(tr4, 4 * leaf + 2), d = cld4(tr4, 4 * leaf + 3);
@@ -477,7 +455,6 @@ __device__ __forceinline__ bool quad_walk(const RtwShapeDev& sh, const TravCtx& 
 // ballot, and candidate leaves are triangle-tested four at a time.  A triangle test must see the segment
 // length left by every earlier accepted hit (the reference tests them one after another), so after an
 // accept the later lanes of the group are tested again with the shortened segment.
-#ifndef RTW_HOST_EMUL
 __device__ __forceinline__ int quad_bcast(int v, int k)      // value of lane k of this lane's quartet
 {
     const int b0 = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
@@ -590,13 +567,11 @@ __device__ __forceinline__ bool quad_walk4(const RtwShapeDev& sh, const TravCtx&
     }
     return any;
 }
-#endif
 
 // ---- 16-wide walk, sixteen lanes per ray ----------------------------------------------------------------
 // Same scheme as quad_walk4 with a 16-slot node per step: lane k of the group tests slot k, the hit mask is the
 // group's 16 bits of the wave ballot, candidates are triangle-tested sixteen at a time.  A ray needs ~4x fewer
 // dependent steps than with quartets, which is what matters when there are too few rays to fill the GPU.
-#ifndef RTW_HOST_EMUL
 // EXACT: for rays that are not "tame": the reference's own box test (skipped axes, Math::Min/Max), no pruning.
 template <bool STATS, bool LDSW, bool EXACT>
 __device__ __forceinline__ bool wide_walk16(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
@@ -704,7 +679,6 @@ __device__ __forceinline__ bool wide_walk16(const RtwShapeDev& sh, const TravCtx
     }
     return any;
 }
-#endif
 
 // ---- RTexture::Sample (Src/Texture.cpp:23-57) on RGBA8 texels + the host LUT ---------------------
 __device__ __forceinline__ void texel_fetch(const uint32_t* __restrict__ tex, const float* __restrict__ lut, int idx, float& r, float& g, float& b, float& a)
@@ -882,16 +856,13 @@ __device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, c
     bool any;
     Counters walk = { 0, 0, 0, 0, 0, 0 };
     const bool tame = ray_is_tame(r);
-#ifndef RTW_HOST_EMUL
     if (LPR == 16 && !tame && sc->traversal != 0 && sh.n_wides > 0) {
         if (LDSQ && first_shape) any = wide_walk16<STATS, true, true>(sh, tc, r, false, cur, pos, slot, walk);
         else any = wide_walk16<STATS, false, true>(sh, tc, r, false, cur, pos, slot, walk);
         if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
     } else
-#endif
     if (tame) {
         if (sc->traversal != 0 && sh.n_quads > 0) {
-#ifndef RTW_HOST_EMUL
             if (LPR == 16 && sh.n_wides > 0) {
                 if (LDSQ && first_shape) any = wide_walk16<STATS, true, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
                 else any = wide_walk16<STATS, false, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
@@ -901,7 +872,6 @@ __device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, c
                 else any = quad_walk4<STATS, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
                 if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
             } else
-#endif
                 any = quad_walk<STATS>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
         } else {
             any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, walk);
@@ -1265,18 +1235,14 @@ __device__ __forceinline__ uint32_t pack_pixel(const float* __restrict__ thr, f3
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
-#ifndef RTW_HOST_EMUL
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-#endif
     return v;
 }
 // counters: one atomic per wave and counter (the whole wave must call this together)
 __device__ __forceinline__ void flush_counters(const RtwSceneDev* __restrict__ sc, const Counters& ct)
 {
     const uint32_t r = wave_sum(ct.rays), b = wave_sum(ct.boxes), t = wave_sum(ct.tris), h = wave_sum(ct.hits), x = wave_sum(ct.tex), c = wave_sum(ct.cams);
-#ifndef RTW_HOST_EMUL
     if ((threadIdx.x & 63) != 0) return;
-#endif
     if (!sc->stats) return;
     atomicAdd(&sc->stats[0], (unsigned long long)r);
     atomicAdd(&sc->stats[1], (unsigned long long)b);
@@ -1390,10 +1356,6 @@ struct PipeBufs {
 // like wave_push, returns the index the value was stored at (or 0xFFFFFFFF)
 __device__ __forceinline__ uint32_t wave_push_slot(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
 {
-#ifdef RTW_HOST_EMUL
-    if (!flag) return 0xFFFFFFFFu;
-    list[*counter] = value; return (*counter)++;
-#else
     const unsigned long long m = __ballot(flag);
     if (m == 0ull) return 0xFFFFFFFFu;
     const int lane = (int)(threadIdx.x & 63u);
@@ -1405,14 +1367,10 @@ __device__ __forceinline__ uint32_t wave_push_slot(uint32_t* __restrict__ list, 
     const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     list[at] = value;
     return at;
-#endif
 }
 
 __device__ __forceinline__ void wave_push(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
 {
-#ifdef RTW_HOST_EMUL
-    if (flag) list[(*counter)++] = value;
-#else
     const unsigned long long m = __ballot(flag);
     if (m == 0ull) return;
     const int lane = (int)(threadIdx.x & 63u);
@@ -1421,7 +1379,6 @@ __device__ __forceinline__ void wave_push(uint32_t* __restrict__ list, uint32_t*
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
     base = (uint32_t)__shfl((int)base, leader);
     if (flag) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
-#endif
 }
 
 __device__ __forceinline__ f3 sky_color(float dir_y)        // Src/RayTracerScene.cpp:92-93
@@ -1480,9 +1437,7 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
             float t0, t1;
             const bool inbox = live && slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1);
             if (STATS && live) ct.boxes++;
-#ifndef RTW_HOST_EMUL
             if (__ballot(inbox) == 0ull) continue;
-#endif
             float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
             const bool any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
             if (any) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
@@ -1529,11 +1484,8 @@ __global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restr
 template <bool STATS, bool LDSQ, int NT, int LPR, int MINW = (LPR == 16 ? 4 : (NT <= 256 ? 4 : 2))>
 __global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
 {
-#ifdef RTW_HOST_EMUL
-    (void)sc; (void)pb; (void)p; (void)lds_quad_count;
-#else
     __shared__ uint32_t trav_words[(LPR == 16 ? (RTW_WIDE_STACK + RTW_WIDE_CAND) : (RTW_QUAD_STACK + RTW_CAND_CAP)) * (NT / LPR)];
-    extern __shared__ float lds_quads[];
+    HIP_DYNAMIC_SHARED(float, lds_quads);
     // the grid is sized for the worst case (every sample queued); blocks past the real queue leave at once
     if (blockIdx.x * (uint32_t)(NT / LPR) >= pb.counters[0]) return;
 #ifdef RTW_TIMING
@@ -1586,7 +1538,6 @@ __global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __res
     }
 #endif
     if (STATS) flush_counters(sc, ct);
-#endif
 }
 
 // ======================================================================================================
@@ -1618,7 +1569,6 @@ __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32
 // pass index of a replayed launch graph.  Every block has read what it needs of both before it takes its ticket.
 __device__ __forceinline__ void pass_epilogue(const PipeBufs& pb, const RtwRenderParams& p, uint32_t n_blocks)      // n_blocks: the blocks that call this
 {
-#ifndef RTW_HOST_EMUL
     if (p.self_clean) {
         __shared__ uint32_t last_block;
         __syncthreads();
@@ -1633,7 +1583,6 @@ __device__ __forceinline__ void pass_epilogue(const PipeBufs& pb, const RtwRende
     } else if (p.pass_ptr && blockIdx.x == 0 && threadIdx.x == 0) {
         *p.pass_ptr += 1;           // (resolve_kernel only: nothing in it reads the pass index)
     }
-#endif
 }
 
 // RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94) for one path whose segment has just been traced: shade the
@@ -1789,7 +1738,6 @@ __global__ __launch_bounds__(256, 3) void shade_kernel(const RtwSceneDev* __rest
     if (last) pass_epilogue(pb, p, gridDim.x);     // resolve_inline: this is the pass's last launch
 }
 
-#ifndef RTW_HOST_EMUL
 template <bool STATS>
 __global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
@@ -1838,13 +1786,10 @@ __global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restric
     }
     if (STATS) flush_counters(sc, ct);
 }
-#endif
 
-#ifndef RTW_HOST_EMUL
 #include "rtw_wave_kernels.h"
 #include "rtw_group_kernels.h"
 #include "rtw_build_kernels.h"
-#endif
 
 __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
                                                       uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
@@ -1920,7 +1865,6 @@ __global__ void texture_sample_kernel(const RtwSceneDev* __restrict__ sc, int sh
 
 }  // namespace
 
-#ifndef RTW_HOST_EMUL
 // ---- launch wrappers ---------------------------------------------------------------------------------------
 namespace rtw {
 
@@ -2587,4 +2531,3 @@ int launch_texture_sample(const RtwSceneDev* sc, int shape, int mat, const float
 }
 
 }  // namespace rtw
-#endif  // RTW_HOST_EMUL

@@ -555,7 +555,7 @@ __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __rest
 template <bool STATS, bool AN, int NT, int CAP, int STAGE>
 __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int staged_shape, int lead)
 {
-    extern __shared__ uint32_t gt_dyn[];                 // [CAP * NT candidate words | staged records]
+    HIP_DYNAMIC_SHARED(uint32_t, gt_dyn);                 // [CAP * NT candidate words | staged records]
     uint32_t* cand = gt_dyn;
     // lead > 0: the scene's first `lead` shapes were tested by the lane that set the segment up; the list holds the rays that go on, their records the state so far
     const uint32_t nl = lead > 0 ? gb.counters[24 + round] : gb.counters[round];
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
 template <bool STATS, int NT, int CAP, int STAGE>
 __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
 {
-    extern __shared__ uint32_t gt_dyn[];                 // [CAP * NT candidate words | staged records]
+    HIP_DYNAMIC_SHARED(uint32_t, gt_dyn);                 // [CAP * NT candidate words | staged records]
     uint32_t* cand = gt_dyn;
     const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
     const RtwShapeDev& sh = sc->shapes[0];
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
 template <bool STATS, bool AN, int NT>
 __global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int from_overflow, int lead)
 {
-    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
+    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
     const uint32_t nl = from_overflow ? gb.counters[40 + round] : (lead > 0 ? gb.counters[24 + round] : gb.counters[round]);
     const uint32_t n = nl < gb.capacity ? nl : gb.capacity;
     if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;

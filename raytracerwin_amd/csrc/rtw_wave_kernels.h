@@ -546,7 +546,7 @@ template <bool STATS, int STAGE, int NT, bool AN = false, bool FINISH = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round,
                                                                                               int closes_pass = 0)
 {
-    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
+    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
     __shared__ float thr[FINISH ? 256 : 1];
     if (FINISH && p.resolve_inline) { for (int i = (int)threadIdx.x; i < 256; i += NT) thr[FINISH ? i : 0] = sc->gamma_thr[i]; __syncthreads(); }
     const bool from_queue = p.direct_slots && round == 0;       // with direct slots the path queue IS round 0's trace list
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trac
 template <bool STATS, int NT>
 __global__ __launch_bounds__(NT) void trace_wave_lead_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int chunk_shift)
 {
-    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
+    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
     const bool from_queue = p.direct_slots && round == 0;
     const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round];
     const uint32_t chunk = 1u << chunk_shift;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(NT) void trace_wave_lead_kernel(const RtwSceneDev* 
 template <bool STATS, int STAGE, int NT, bool RESUME>
 __global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathwave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p)
 {
-    extern __shared__ uint32_t wave_dyn[];              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
+    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
     const uint32_t B = (uint32_t)p.wave_paths;
     const uint32_t nq = RESUME ? pb.counters[4] : pb.counters[0];
     const uint32_t n = nq < pb.capacity ? nq : pb.capacity;

@@ -288,16 +288,47 @@ def test_analytic_shapes_keep_insertion_order_and_the_reference_culling_boxes(or
         s.AddShape(R.RSphere.Create((0, 0, 0), 1.0))        # committed
 
 
-def test_device_code_under_address_and_ub_sanitizers(tmp_path):
-    """tests/cpu_emul compiles rtw_device.hip for the HOST (RTW_HOST_EMUL) with -fsanitize=address,undefined and runs the one-thread-per-pixel
-    kernel -- the ray / box / triangle / texture / material / path code every pipeline shares -- over small frames of a plain and a textured mesh
-    (GPU sanitizers are not available on the pool).  Any out-of-bounds access or undefined operation aborts the run."""
+def _sanitizer_build():
     import subprocess
     here = os.path.join(ROOT, "tests", "cpu_emul")
-    subprocess.check_call(["make", "-C", here], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    exe = os.path.join(here, "_build", "emul_main")
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    for args in (["TorusKnot.obj", "96", "54", "2", "4"], ["unitychan.obj", "64", "64", "1", "3"], ["BlenderMonkey.obj", "48", "48", "4", "2", "0", "48", "0", "0"]):
-        r = subprocess.run([exe, asset(args[0])] + args[1:], capture_output=True, text=True, env=env)
-        assert r.returncode == 0 and "emul ok" in r.stdout, r.stderr[-2000:]
-        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+    subprocess.check_call(["make", "-C", here, "-j4", "all"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asan = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang++", "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    assert os.path.exists(asan), asan
+    return here, asan
+
+
+def test_sanitizer_harness_catches_what_it_should():
+    """tests/cpu_emul runs GPU threads as fibers and cross-lane operations as rendezvous of a wave (shim/hip/hip_runtime.h, hipemu_rt.cpp).
+    Before trusting a clean run of the product under it: a kernel that writes past its buffer, one that reads past the launch's LDS and one
+    whose wave splits around a cross-lane operation must each abort; a correct wave-level scan must pass."""
+    import subprocess
+    here, asan = _sanitizer_build()
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(asan), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+    exe = os.path.join(here, "_build", "selftest")
+    r = subprocess.run([exe, "ok"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stderr[-2000:]
+    for mode, sign in (("oob_global", "heap-buffer-overflow"), ("oob_lds", "heap-buffer-overflow"), ("divergent", "divergent wave operation")):
+        r = subprocess.run([exe, mode], capture_output=True, text=True, env=env)
+        assert r.returncode != 0 and sign in r.stderr and "unnoticed" not in r.stdout, (mode, r.stderr[-1500:])
+
+
+def test_product_sources_under_address_and_ub_sanitizers():
+    """GPU sanitizers are not available on the pool, so the product's OWN sources -- rtw_device.hip with every kernel of every pipeline and every
+    launch wrapper, the device tree / bins build, rtwin_capi.cpp -- are compiled for the host against the HIP stand-in of tests/cpu_emul
+    (-fsanitize=address,undefined; "device" buffers and LDS are exactly-sized heap blocks) into librtwin_emul.so, and the Python mirror drives
+    it through the same C ABI: frames of single-mesh and multi-shape scenes (pass-batched default pipeline with each of its trace kernels,
+    the bins + wave pipeline, the one-thread-per-pixel kernel, ragged frames, texel inheritance, preview), the device build, the query entry
+    points.  An out-of-bounds access, an undefined operation or a wave that splits around a cross-lane operation aborts the run; every frame
+    must also equal the oracle's bit for bit (the same IEEE operations in the same order, here on x86).  Three processes, ~40 s each."""
+    import subprocess
+    import sys
+    here, asan = _sanitizer_build()
+    env = dict(os.environ, RTW_LIB=os.path.join(here, "_build", "librtwin_emul.so"), LD_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    groups = [["device_build"], ["textured", "quirk", "setup_scene", "room", "tris"], ["mirror", "preview", "ragged", "shapes", "trace_variants", "queries"]]
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "emul_cases.py")] + g, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for g in groups]
+    for g, p in zip(groups, procs):
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0 and ("emul ok: %d cases" % len(g)) in out, (g, out[-1500:], err[-3000:])
+        assert "runtime error" not in err and "AddressSanitizer" not in err, err[-3000:]
