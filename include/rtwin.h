@@ -101,7 +101,7 @@ int rtw_context_synchronize(rtw_context* ctx);
  *   pipelines 1, 2: "packets" (1) camera rays traced as 64-ray packets inside the primary kernel; "path_lanes" lanes per
  *                   ray in the path kernel: 16 (default), 4 or 1; "path_variant": occupancy variants of the path kernel.
  *   "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms).
- *   Pass-batched pipeline (4): "group_max" (64) passes per group at most (a power of two), "group_paths" (4 Mi) paths a launch should hold;
+ *   Pass-batched pipeline (4): "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold;
  *                   "trace_stage" (1) the trace blocks stage the first mesh's upper tree levels in LDS; "trace_persist" (1) one-mesh scenes: persistent
  *                   trace waves that refill their lanes; "wave_below" (160 000) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
  *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (256) big trees: a ray's node visits in the

@@ -138,8 +138,8 @@ struct rtw_context {
     int known_goverflow[24];
     int known_gtrace[16];
     int visit_budget = 256;             // one-mesh scenes with a big tree: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
-    int group_paths = 4 << 20;          // passes are grouped until a launch holds about this many paths ...
-    int group_max = 64;                 // ... and at most this many passes (a power of two)
+    int group_paths = 16 << 20;         // passes are grouped until a launch holds about this many paths ...
+    int group_max = 256;                // ... and at most this many passes (a power of two)
     int wide_below = 0;                 // trace rounds with at least wave_below and fewer than this many rays run sixteen lanes per ray on the 16-wide tree (0: never)
     int wave_below = 160000;            // trace rounds with fewer rays than this (previous group's count) run a wave per ray instead of a ray per lane
     int device_build = 1;               // rtw_scene_commit builds the tree (KdNode::Build's decisions) and the layouts derived from it on the device (0: on the host)
@@ -308,7 +308,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "trace_stage") == 0) { ctx->trace_stage = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "group_max") == 0) {
-        if (value < 1 || value > 64 || (value & (value - 1)) != 0) return fail(RTW_ERR_INVALID, "group_max must be a power of two in 1..64");
+        if (value < 1 || value > 256 || (value & (value - 1)) != 0) return fail(RTW_ERR_INVALID, "group_max must be a power of two in 1..256");
         ctx->group_max = value;
         return RTW_OK;
     }
@@ -1190,10 +1190,10 @@ static int group_passes(const rtw_context* cx, long long paths_per_pass, int rem
 {
     long long k = 1;
     while (k < cx->group_max && k * paths_per_pass < cx->group_paths) k <<= 1;
-    // memory: at most ~6 GiB of workspace and 2^30 slots
+    // memory: at most ~24 GiB of workspace (of 288) and 2^30 slots
     for (;;) {
         const size_t bytes = rtw::group_workspace_bytes((size_t)(paths_per_pass * k), max_bounce, carry, nullptr);
-        if (k == 1 || (bytes <= ((size_t)6 << 30) && paths_per_pass * k < ((long long)1 << 30))) break;
+        if (k == 1 || (bytes <= ((size_t)24 << 30) && paths_per_pass * k < ((long long)1 << 30))) break;
         k >>= 1;
     }
     return (int)(k < remaining ? k : remaining);

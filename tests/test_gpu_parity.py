@@ -647,7 +647,25 @@ def test_k_batched_passes_equal_pass_by_pass(ctx, mesh, W, H, ns, depth, world):
             assert (bits(a) == bits(ra)).all() and (b == rb).all(), (gmax, calls)
             fb.close()
     finally:
-        ctx.set_option("group_max", 64)
+        ctx.set_option("group_max", 256)
+
+
+@pytest.mark.gpu
+def test_groups_of_more_than_64_passes(ctx):
+    """The largest groups the default policy forms (256 passes: a rank's share of a frame at 8 ranks, small frames): 200 passes of a small frame
+    in one group (8 bits of a slot hold the pass), against one call per pass through the single kernel."""
+    s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0))
+    W, H, depth, npass = 320, 180, 4, 200
+    ctx.set_option("pipeline", 0)
+    ref = R.Framebuffer(ctx, W, H)
+    for p in range(npass):
+        R.ThreadWorker_Render(s, ref, 0, W * H - 1, depth, None, p, 1, 31)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    fb = R.Framebuffer(ctx, W, H)
+    s.render_passes(fb, 10, 0, 1, depth, None, 0, npass, 1, 31)
+    assert ctx.last_pass_pipeline() == 4 and ctx.last_group_passes() == npass
+    assert (bits(fb.read_float()) == bits(ra)).all() and (fb.resolve_argb() == rb).all()
 
 
 @pytest.mark.gpu
@@ -670,7 +688,7 @@ def test_k_batched_passes_multi_shape_scenes(ctx, tag, W, H, ns, depth):
         assert ctx.last_pass_pipeline() == 4
         assert (bits(fb.read_float()) == bits(ra)).all() and (fb.resolve_argb() == rb).all(), gmax
         fb.close()
-    ctx.set_option("group_max", 64)
+    ctx.set_option("group_max", 256)
 
 
 @pytest.mark.gpu
