@@ -59,6 +59,34 @@ __device__ __forceinline__ bool group_xy(const RtwGroupParams& g, int wt, int la
     return live && pixel >= g.range_begin && pixel <= g.range_end;
 }
 
+// A list push by a whole BLOCK of NW waves (every thread calls it, the same number of times): one atomic per block instead of one per wave.
+// The lists of a round have one counter; ~20 000 waves pushing to it one atomic each measured 6 us per pass of the C2 primary kernel (a third
+// of it): returning atomics on one address execute one after another in the L2.  `mine` = entries this wave appends (wave-uniform);
+// returns the index of the wave's first entry.  part: NW + 1 words of LDS.
+template <int NW>
+__device__ __forceinline__ uint32_t block_reserve(uint32_t* __restrict__ counter, uint32_t mine, uint32_t* part)
+{
+    const uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) part[w] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < NW; i++) { const uint32_t c = part[i]; part[i] = tot; tot += c; }
+        part[NW] = tot != 0u ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t at = part[NW] + part[w];
+    __syncthreads();            // the words are free again for the next call
+    return at;
+}
+template <int NW>
+__device__ __forceinline__ void block_push(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value, uint32_t* part)
+{
+    const unsigned long long m = __ballot(flag);
+    const uint32_t at = block_reserve<NW>(counter, (uint32_t)__popcll(m), part);
+    if (flag) list[at + (uint32_t)mbcnt(m)] = value;
+}
+
 // RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94) for one path whose segment has just been traced (r0 = hit position +
 // distance, r1 = shape, leaf slot or part, carry).  Returns true when the path goes on (ray, rng, depth, nlev updated, its level
 // pushed); false when it ends: L is its radiance, the levels folded back in the reference's association order.
@@ -217,6 +245,8 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
     const bool prune = sc->prune != 0;
     const uint32_t total = (uint32_t)g.n_jobs * (uint32_t)g.n_passes;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    __shared__ uint32_t part[5];
+    uint32_t q_out = 0u, tq_out = 0u, b_out = 0u, k_out = 0u;
     if (wave < total) {
         // the passes of a tile are neighbouring waves (its bin list stays hot); jobs in the table's order, heaviest bins first
         const uint32_t jidx = wave / (uint32_t)g.n_passes, kpass = wave - jidx * (uint32_t)g.n_passes;
@@ -368,22 +398,23 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
                 gb.rad[slot] = make_float4(si.x, si.y, si.z, 0.0f);
             }
         }
-        // ONE atomic per wave: round 0's list gets an entry per sample that goes on
+        q_out = queued; tq_out = tqueued; b_out = b; k_out = kpass;
+    }
+    {
+        // ONE atomic per BLOCK: round 0's list gets an entry per sample that goes on (every wave of the block comes here, also one without a job)
+        const uint32_t queued = q_out, tqueued = tq_out, b = b_out, kpass = k_out;
+        const int lane = lane_id();
         const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
                                  m3 = __ballot((queued & 8u) != 0u);
-        if ((m0 | m1 | m2 | m3) != 0ull) {
-            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
-            uint32_t base = 0u;
-            if (lane == 0) base = atomicAdd(&gb.counters[0], c0 + c1 + c2 + c3);
-            const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (queued & 1u) gb.list0[qb + (uint32_t)mbcnt(m0)] = group_slot(g, b, (uint32_t)lane, 0u, kpass);
-            if (queued & 2u) gb.list0[qb + c0 + (uint32_t)mbcnt(m1)] = group_slot(g, b, (uint32_t)lane, 1u, kpass);
-            if (queued & 4u) gb.list0[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = group_slot(g, b, (uint32_t)lane, 2u, kpass);
-            if (queued & 8u) gb.list0[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = group_slot(g, b, (uint32_t)lane, 3u, kpass);
-        }
+        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
+        const uint32_t qb = block_reserve<4>(&gb.counters[0], c0 + c1 + c2 + c3, part);
+        if (queued & 1u) gb.list0[qb + (uint32_t)mbcnt(m0)] = group_slot(g, b, (uint32_t)lane, 0u, kpass);
+        if (queued & 2u) gb.list0[qb + c0 + (uint32_t)mbcnt(m1)] = group_slot(g, b, (uint32_t)lane, 1u, kpass);
+        if (queued & 4u) gb.list0[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = group_slot(g, b, (uint32_t)lane, 2u, kpass);
+        if (queued & 8u) gb.list0[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = group_slot(g, b, (uint32_t)lane, 3u, kpass);
         if (AN && p.lead_shapes > 0) {       // the subset that still has to be traced
             for (uint32_t i = 0; i < (uint32_t)p.sub_samples; i++)
-                wave_push(gb.tlist0, &gb.counters[24], (tqueued >> i) & 1u, group_slot(g, b, (uint32_t)lane, i, kpass));
+                block_push<4>(gb.tlist0, &gb.counters[24], (tqueued >> i) & 1u, group_slot(g, b, (uint32_t)lane, i, kpass), part);
         }
     }
     if (STATS) flush_counters(sc, ct);
@@ -935,8 +966,9 @@ __global__ __launch_bounds__(256, 3) void gshade_kernel(const RtwSceneDev* __res
     const int npix = p.width * p.height;
     const uint32_t phase = table_phase(p.seed);
     const uint32_t kmask = (1u << g.kshift) - 1u;
+    __shared__ uint32_t part[5];
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    const uint32_t trips = (n + nthreads - 1) / nthreads;        // wave-uniform trip count: every lane joins the pushes
+    const uint32_t trips = (n + nthreads - 1) / nthreads;        // grid-uniform trip count: every thread joins the pushes
     for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < trips; it++, k += nthreads) {
         const bool live = k < n;
         const uint32_t slot = live ? src[k] : 0u;
@@ -969,8 +1001,8 @@ __global__ __launch_bounds__(256, 3) void gshade_kernel(const RtwSceneDev* __res
                 }
             } else { const f3 c = mk(0, 0, 0) + L; gb.rad[slot] = make_float4(c.x, c.y, c.z, 0.0f); }
         }
-        wave_push(dst, &gb.counters[round], go_on, slot);
-        if (AN && p.lead_shapes > 0) wave_push(round & 1 ? gb.tlist1 : gb.tlist0, &gb.counters[24 + round], trace_on, slot);
+        block_push<4>(dst, &gb.counters[round], go_on, slot, part);        // (the trip count is the same for every thread of the grid)
+        if (AN && p.lead_shapes > 0) block_push<4>(round & 1 ? gb.tlist1 : gb.tlist0, &gb.counters[24 + round], trace_on, slot, part);
     }
     if (STATS) flush_counters(sc, ct);
 }
