@@ -1233,6 +1233,30 @@ __device__ __forceinline__ uint32_t pack_pixel(const float* __restrict__ thr, f3
     return (255u << 24) | (gamma_fix(thr, c.x, gx, x0, x1) << 16) | (gamma_fix(thr, c.y, gy, y0, y1) << 8) | gamma_fix(thr, c.z, gz, z0, z1);
 }
 
+// pack_pixel for a pixel whose previous pass's bytes are known (the sky kernel keeps a pixel in registers for all passes of a group): an
+// averaged colour moves by less than a threshold step from one pass to the next, so the bracket [thr[k], thr[k + 1]) of the previous byte usually
+// still holds -- two compares instead of log2 / exp2 and two table reads; when it does not, the walk from the old k is a step or two.
+// The value is gamma_channel's in every case: 0 for !(c > 0) (NaN too), 255 for c >= 1, else the largest k with thr[k] <= c.
+struct GammaBracket { int k; float t0, t1; };      // k < 0: nothing cached yet
+__device__ __forceinline__ uint32_t gamma_bracketed(const float* __restrict__ thr, float c, GammaBracket& g)
+{
+    if (!(g.t0 <= c && c < g.t1)) {
+        int k = g.k < 0 ? gamma_guess(c) : g.k;
+        if (!(c > 0.0f)) k = 0;
+        else if (c >= 1.0f) k = 255;
+        else {
+            while (k < 255 && thr[k + 1] <= c) k++;
+            while (k > 0 && thr[k] > c) k--;
+        }
+        g.k = k; g.t0 = thr[k]; g.t1 = k < 255 ? thr[k + 1] : __int_as_float(0x7F800000);
+    }
+    return (uint32_t)g.k;
+}
+__device__ __forceinline__ uint32_t pack_pixel_bracketed(const float* __restrict__ thr, f3 c, GammaBracket* g)
+{
+    return (255u << 24) | (gamma_bracketed(thr, c.x, g[0]) << 16) | (gamma_bracketed(thr, c.y, g[1]) << 8) | gamma_bracketed(thr, c.z, g[2]);
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

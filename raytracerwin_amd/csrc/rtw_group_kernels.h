@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void gsky_kernel(const float* __restrict__ gam
         if (!p.preview) acc = accum[pixel];
         f3 sum = mk(acc.x, acc.y, acc.z);
         int n = __float_as_int(acc.w);
+        GammaBracket gb3[3];
+        for (int c = 0; c < 3; c++) { gb3[c].k = -1; gb3[c].t0 = 1.0f; gb3[c].t1 = 0.0f; }       // an empty bracket: the first pass looks its bytes up
         for (int k = 0; k < g.n_passes; k++) {
             f3 csum = mk(0, 0, 0);
             for (int i = 0; i < p.sub_samples; i++) {
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(256) void gsky_kernel(const float* __restrict__ gam
             }
             const f3 c = p.sub_samples == 1 ? csum : csum / (float)p.sub_samples;          // x / 1.0f == x
             uint32_t packed;
-            if (p.preview) packed = pack_pixel(thr, c);
-            else { sum = sum + c; n++; packed = pack_pixel(thr, n == 1 ? sum : sum / (float)n); }
+            if (p.preview) packed = pack_pixel_bracketed(thr, c, gb3);
+            else { sum = sum + c; n++; packed = pack_pixel_bracketed(thr, n == 1 ? sum : sum / (float)n, gb3); }
             __builtin_nontemporal_store(packed, &argb[pixel]);      // bitcolor[] is written every pass (Src/RayTracerProgram.cpp:185)
         }
         if (!p.preview) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
