@@ -652,8 +652,8 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
 
 // ---- the same round for a scene that is ONE mesh: persistent waves that refill their lanes ------------------------------------
 // In the kernel above a wave walks 64 rays in lock step until the slowest is done (the mean lane is busy ~40 % of that time) and a
-// block keeps its CU until its slowest wave is done.  Here the grid holds one block per CU and every wave owns an equal contiguous
-// share of the list: whenever RTW_GT_REFILL lanes have finished their walk (or some lane's candidate list is full) the wave runs the
+// block keeps its CU until its slowest wave is done.  Here the grid holds one block per CU, every block owns an interleaved share of
+// the list and its waves draw 64-entry batches from it through a counter in LDS: whenever RTW_GT_REFILL lanes have finished their walk (or some lane's candidate list is full) the wave runs the
 // noted leaves' triangle tests for all its lanes, writes the finished lanes' hit records and hands those lanes new rays -- out of the
 // 64 it fetched ahead into registers while it walked (one atomic cursor for all waves was measured: 60 k same-address atomics per
 // launch serialise, 14 us per refill).  A lane's sequence of box tests and triangle tests is untouched by what its neighbours do.
@@ -666,14 +666,22 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
     const RtwShapeDev& sh = sc->shapes[0];
     const float4* lnodes = nullptr; int ltop = 0;
+    // Who takes which 64-entry batch of the list.  A tree that lives in LDS entirely (STAGE 2: the config meshes TorusKnot and BlenderMonkey):
+    // static, wave w of the grid takes batches w, w + waves, ... -- neighbouring batches (neighbours on the screen) on neighbouring waves.
+    // A larger tree (unitychan: most node records come through L2, a batch's cost varies more): every block owns batches b, b + blocks, ...
+    // and its waves DRAW them in turn from a counter in LDS, so that a wave that met cheap rays takes more.  Measured at 20 passes per group:
+    // dynamic C4 0.277 -> 0.261, C5 1.126 -> 1.053 ms per pass, but C2 0.057 -> 0.064 and C3 0.155 -> 0.157 (hence the split).
+    constexpr bool DRAW = STAGE != 2;
+    __shared__ uint32_t blk_next;
+    if (threadIdx.x == 0) blk_next = (uint32_t)(NT / 64);       // each wave starts with the batch of its index in the block
     if (STAGE) {
         ltop = sh.tnodes_top;
         float4* dst = reinterpret_cast<float4*>(gt_dyn + CAP * NT);
         const float4* src4 = reinterpret_cast<const float4*>(sh.tnodes);
         for (int k = (int)threadIdx.x; k < ltop * 2; k += NT) dst[k] = gld4(src4, (size_t)k);
         lnodes = dst;
-        __syncthreads();
     }
+    __syncthreads();
     constexpr bool ALLDS = STAGE == 2;
     const float4* nd4 = reinterpret_cast<const float4*>(sh.tnodes);
     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
@@ -691,16 +699,17 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     int i = n_nodes, leaf_out = -1, ncand = 0, visits = 0;
     // the wave's share of the list: every nw-th batch of 64 entries (neighbouring entries come from neighbouring pixels and cost alike:
     // contiguous shares were measured 2 x out of balance), fetched one batch ahead into staging registers
-    uint32_t rnext, st_count, st_used = 0u, st_slot = 0u;
+    uint32_t st_count, st_used = 0u, st_slot = 0u;
     float4 st_s0 = make_float4(0.f, 0.f, 0.f, 0.f), st_s1 = st_s0;
-    const uint32_t rstride = gridDim.x * (uint32_t)(NT / 64) * 64u;
+    const uint32_t n_batches = (n + 63u) >> 6;
+    uint32_t static_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)(NT / 64) + (threadIdx.x >> 6))) + gridDim.x * (uint32_t)(NT / 64);
     {
-        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)(NT / 64) + (threadIdx.x >> 6)));
-        rnext = wv * 64u;
-        st_count = rnext < n ? (n - rnext < 64u ? n - rnext : 64u) : 0u;
-        const uint32_t k = rnext + (uint32_t)lane_id();
-        if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
-        rnext += rstride;
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const uint32_t batch = DRAW ? j * gridDim.x + blockIdx.x : blockIdx.x * (uint32_t)(NT / 64) + j;
+        const uint32_t first = batch * 64u;
+        st_count = batch < n_batches ? (n - first < 64u ? n - first : 64u) : 0u;
+        const uint32_t k = first + (uint32_t)lane_id();
+        if (batch < n_batches && k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
     }
 #ifdef RTW_TIMING
     int dbg_walk = 0, dbg_tri = 0, dbg_ev = 0; unsigned long long dbg_refill = 0ull;
@@ -738,10 +747,19 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                 }
                 st_used += take;
                 if (st_used == st_count) {          // fetch the next 64 now: they arrive while the wave walks
-                    st_count = rnext < n ? (n - rnext < 64u ? n - rnext : 64u) : 0u; st_used = 0u;
-                    const uint32_t k = rnext + (uint32_t)lane_id();
-                    if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
-                    rnext += rstride;
+                    uint32_t batch;
+                    if (DRAW) {
+                        uint32_t j = 0u;
+                        if (lane_id() == 0) j = atomicAdd(&blk_next, 1u);
+                        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+                        batch = j < 0x00FFFFFFu ? j * gridDim.x + blockIdx.x : 0xFFFFFFFFu;        // (the counter cannot wrap: one failed draw per wave ends it)
+                    } else {
+                        batch = static_next; static_next += gridDim.x * (uint32_t)(NT / 64);
+                    }
+                    const uint32_t first = batch * 64u;
+                    st_count = batch < n_batches ? (n - first < 64u ? n - first : 64u) : 0u; st_used = 0u;
+                    const uint32_t k = first + (uint32_t)lane_id();
+                    if (batch < n_batches && k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
                 }
             }
         }
