@@ -657,6 +657,29 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
 // noted leaves' triangle tests for all its lanes, writes the finished lanes' hit records and hands those lanes new rays -- out of the
 // 64 it fetched ahead into registers while it walked (one atomic cursor for all waves was measured: 60 k same-address atomics per
 // launch serialise, 14 us per refill).  A lane's sequence of box tests and triangle tests is untouched by what its neighbours do.
+// Entry of the round's list that this lane stages for batch `batch` (n entries, n_batches = ceil(n / 64)); count = the batch's entries (they
+// sit in lanes 0 .. count - 1); 0xFFFFFFFF: none.  SPREAD: batch b is entries b, b + n_batches, b + 2 n_batches, ... (lane l reads the l-th
+// 64th of the list): neighbours in the list are neighbours on the screen and cost alike, so 64 consecutive entries make cheap batches and
+// dear ones (per-wave durations 2 x apart, the kernel as slow as its slowest wave) while a spread batch is a sample of the whole list
+// (slowest wave / mean 1.84 -> 1.41 on C2; the waves run ~13 % more iterations each, their lanes' rays being less alike).
+#ifndef RTW_GT_SPREAD
+#define RTW_GT_SPREAD 1
+#endif
+template <bool SPREAD>
+__device__ __forceinline__ uint32_t batch_entry(uint32_t batch, uint32_t n_batches, uint32_t n, uint32_t& count)
+{
+    count = 0u;
+    if (batch >= n_batches) return 0xFFFFFFFFu;
+    const uint32_t lane = (uint32_t)lane_id();
+    if (SPREAD) {
+        count = 63u * n_batches + batch < n ? 64u : (n - batch + n_batches - 1u) / n_batches;      // lanes l with l * n_batches + batch < n
+        const uint32_t k = lane * n_batches + batch;
+        return k < n ? k : 0xFFFFFFFFu;
+    }
+    const uint32_t first = batch * 64u;
+    count = n - first < 64u ? n - first : 64u;
+    return first + lane < n ? first + lane : 0xFFFFFFFFu;
+}
 #define RTW_GT_REFILL 16
 template <bool STATS, int NT, int CAP, int STAGE>
 __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
@@ -672,6 +695,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     // and its waves DRAW them in turn from a counter in LDS, so that a wave that met cheap rays takes more.  Measured at 20 passes per group:
     // dynamic C4 0.277 -> 0.261, C5 1.126 -> 1.053 ms per pass, but C2 0.057 -> 0.064 and C3 0.155 -> 0.157 (hence the split).
     constexpr bool DRAW = STAGE != 2;
+    constexpr bool SPREAD = RTW_GT_SPREAD != 0 && STAGE == 2;       // (measured: bounce rounds -4 % on C2, -2.5 % on C3; +1 % on C4 / C5, whose deep node records like neighbours together)
     __shared__ uint32_t blk_next;
     if (threadIdx.x == 0) blk_next = (uint32_t)(NT / 64);       // each wave starts with the batch of its index in the block
     if (STAGE) {
@@ -706,10 +730,8 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     {
         const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const uint32_t batch = DRAW ? j * gridDim.x + blockIdx.x : blockIdx.x * (uint32_t)(NT / 64) + j;
-        const uint32_t first = batch * 64u;
-        st_count = batch < n_batches ? (n - first < 64u ? n - first : 64u) : 0u;
-        const uint32_t k = first + (uint32_t)lane_id();
-        if (batch < n_batches && k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
+        const uint32_t k = batch_entry<SPREAD>(batch, n_batches, n, st_count);
+        if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
     }
 #ifdef RTW_TIMING
     int dbg_walk = 0, dbg_tri = 0, dbg_ev = 0; unsigned long long dbg_refill = 0ull;
@@ -756,10 +778,9 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     } else {
                         batch = static_next; static_next += gridDim.x * (uint32_t)(NT / 64);
                     }
-                    const uint32_t first = batch * 64u;
-                    st_count = batch < n_batches ? (n - first < 64u ? n - first : 64u) : 0u; st_used = 0u;
-                    const uint32_t k = first + (uint32_t)lane_id();
-                    if (batch < n_batches && k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
+                    st_used = 0u;
+                    const uint32_t k = batch_entry<SPREAD>(batch, n_batches, n, st_count);
+                    if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
                 }
             }
         }
@@ -975,7 +996,10 @@ __global__ __launch_bounds__(256) void gtrace_wide_kernel(const RtwSceneDev* __r
 
 // ---- shading of one round's hits: a path per lane ---------------------------------------------------------------------------------
 template <bool STATS, bool AN>
-__global__ __launch_bounds__(256, 3) void gshade_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, RtwGroupParams g, int round)
+#ifndef RTW_GSHADE_MINB
+#define RTW_GSHADE_MINB 3
+#endif
+__global__ __launch_bounds__(256, RTW_GSHADE_MINB) void gshade_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, RtwGroupParams g, int round)
 {
     // round >= 1: the paths of list (round - 1) have had their segment traced; the ones that go on join list `round`
     const RtwRenderParams& p = g.rp;
