@@ -104,8 +104,9 @@ int rtw_context_synchronize(rtw_context* ctx);
  *   Pass-batched pipeline (4): "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold;
  *                   "trace_stage" (1) the trace blocks stage the first mesh's upper tree levels in LDS; "trace_persist" (1) one-mesh scenes: persistent
  *                   trace waves that refill their lanes; "wave_below" (160 000) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
- *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (256) big trees: a ray's node visits in the
- *                   ray-per-lane kernel before it goes to the wave-per-ray one; "device_build" (1) tree, layouts and screen bins built on the device. */
+ *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (384) one-mesh scenes: a ray's node visits in the
+ *                   ray-per-lane kernel before it goes to the wave-per-ray one (a rare ray that walks a thousand nodes kept its whole wave waiting: the
+ *                   slowest C2 call in 24 went from 1.17 to 0.98 ms), for trees with more than "budget_nodes" (0) nodes; "device_build" (1) tree, layouts and screen bins built on the device. */
 int rtw_context_set_option(rtw_context* ctx, const char* name, int value);
 /* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's three stages -- primary kernel(s),
  * the per-bounce trace / shade launches, resolve -- measured on the context's stream; waits for that pass. */

@@ -419,6 +419,9 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
                 block_push<4>(gb.tlist0, &gb.counters[24], (tqueued >> i) & 1u, group_slot(g, b, (uint32_t)lane, i, kpass), part);
         }
     }
+#ifdef RTW_TIMING
+    if ((threadIdx.x & 63u) == 0u) atomicMax(&g_rtw_timing[6 * 16000], wall_clock64());      // last wave of the primary kernel leaves
+#endif
     if (STATS) flush_counters(sc, ct);
 }
 
@@ -685,6 +688,9 @@ template <bool STATS, int NT, int CAP, int STAGE>
 __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
 {
     HIP_DYNAMIC_SHARED(uint32_t, gt_dyn);                 // [CAP * NT candidate words | staged records]
+#ifdef RTW_TIMING
+    const unsigned long long rtw_entry = wall_clock64();
+#endif
     uint32_t* cand = gt_dyn;
     const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
     const RtwShapeDev& sh = sc->shapes[0];
@@ -900,7 +906,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63u) == 0 && w < 16384 && round == 0) {
             g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = (unsigned long long)dbg_walk;
-            g_rtw_timing[6 * w + 3] = (unsigned long long)dbg_tri; g_rtw_timing[6 * w + 4] = (unsigned long long)dbg_ev; g_rtw_timing[6 * w + 5] = rtw_t0 + dbg_refill;
+            g_rtw_timing[6 * w + 3] = (unsigned long long)dbg_tri; g_rtw_timing[6 * w + 4] = (unsigned long long)dbg_ev; g_rtw_timing[6 * w + 5] = rtw_entry;
         }
     }
 #endif
@@ -1011,6 +1017,9 @@ __global__ __launch_bounds__(256, RTW_GSHADE_MINB) void gshade_kernel(const RtwS
     const uint32_t phase = table_phase(p.seed);
     const uint32_t kmask = (1u << g.kshift) - 1u;
     __shared__ uint32_t part[5];
+#ifdef RTW_TIMING
+    if (round == 1 && g.first_pass == 2 * g.n_passes && (threadIdx.x & 63u) == 0u) atomicMax(&g_rtw_timing[6 * 16000 + 1], 0x7FFFFFFFFFFFFFFFull - wall_clock64());     // first wave of shade(1) enters
+#endif
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     const uint32_t trips = (n + nthreads - 1) / nthreads;        // grid-uniform trip count: every thread joins the pushes
     for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < trips; it++, k += nthreads) {

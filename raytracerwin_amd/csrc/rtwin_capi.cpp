@@ -137,7 +137,8 @@ struct rtw_context {
     int known_ground[32];
     int known_goverflow[24];
     int known_gtrace[16];
-    int visit_budget = 256;             // one-mesh scenes with a big tree: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
+    int budget_nodes = 0;               // ... trees with more nodes than this get the budget
+    int visit_budget = 384;             // one-mesh scenes: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
     int group_paths = 16 << 20;         // passes are grouped until a launch holds about this many paths ...
     int group_max = 256;                // ... and at most this many passes (a power of two)
     int wide_below = 0;                 // trace rounds with at least wave_below and fewer than this many rays run sixteen lanes per ray on the 16-wide tree (0: never)
@@ -301,6 +302,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         return RTW_OK;
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "budget_nodes") == 0) { ctx->budget_nodes = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wide_below") == 0) { ctx->wide_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "device_build") == 0) { ctx->device_build = value ? 1 : 0; return RTW_OK; }
@@ -1259,7 +1261,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.single_mesh = scene->meshes.size() == 1 && scene->meshes[0]->kind == RTW_SHAPE_MESH && !scene->meshes[0]->nodes.empty();
     tune.persist = cx->trace_persist != 0;
     // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
-    tune.visit_budget = (cx->visit_budget > 0 && tune.single_mesh && scene->meshes[0]->nodes.size() > 4096) ? cx->visit_budget : INT32_MAX;
+    tune.visit_budget = (cx->visit_budget > 0 && tune.single_mesh && scene->meshes[0]->nodes.size() > (size_t)cx->budget_nodes) ? cx->visit_budget : INT32_MAX;
     tune.wide_below = cx->wide_below;
     tune.wide_ok = true;
     for (const auto& m : scene->meshes) if (m->kind == RTW_SHAPE_MESH && (m->wides.empty() || m->wide_depth > RTW_WIDE_STACK || m->wides.size() >= 65536)) tune.wide_ok = false;

@@ -71,7 +71,7 @@ def material(rng, depth=0):
 
 
 DEFAULTS = dict(pipeline=4, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1,
-                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=100000, visit_budget=256)
+                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=160000, visit_budget=384)
 
 
 def run(seed_arg, cases, ctx=None, log=print):
@@ -108,7 +108,7 @@ def run(seed_arg, cases, ctx=None, log=print):
                     trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3), lead_split=int(rng.random() < 0.8), resolve_inline=int(rng.random() < 0.8), batch_passes=int(rng.random() < 0.7), finish_in_trace=int(rng.random() < 0.4), auto_fused=int(rng.random() < 0.7))
         # the pass-batched pipeline's own switches: passes per group, staging, persistent waves, the wave-per-ray threshold, the visit budget
         gopts = dict(group_max=int(rng.choice([1, 2, 4, 64, 256])), trace_stage=int(rng.random() < 0.7), trace_persist=int(rng.random() < 0.7),
-                     wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 256])), sky_split=opts["sky_split"])
+                     wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 384])), sky_split=opts["sky_split"])
         res = []
         for pl in (0, 3, 4):
             ctx.set_option("pipeline", pl)
