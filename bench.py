@@ -459,6 +459,14 @@ def main():
         alg_run = algorithmic_bytes(st_run_pass, npix)
         pass_ms = kernel_ms
         traffic = None
+        valu_per_pass = None        # wave-level VALU instructions per pass from the kept PMC summary of this config (SQ_INSTS_VALU, own rocprofv3 run)
+        ip = os.path.join(ROOT, "profiles", "r02_%s_insts.json" % args.config)
+        if args.pipeline == 4 and os.path.exists(ip):
+            try:
+                ins = json.load(open(ip))
+                valu_per_pass = sum(v["SQ_INSTS_VALU"] for v in ins["per_kernel_in_the_timed_call"].values()) / float(ins.get("steps_in_the_timed_call", 20))
+            except Exception:
+                valu_per_pass = None
         tp = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % args.config)
         if os.path.exists(tp) and world == 1:
             try:
@@ -496,8 +504,15 @@ def main():
                          "frac_algorithmic": achieved / HBM_PEAK_GBS,
                          "frac_hbm_measured": (traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "frac_algorithmic_reference_order": alg_ref / world / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "limiter": "not bandwidth: the tree, bins and (small meshes) triangle records stay in LDS / L2 / Infinity Cache, measured HBM traffic is a fraction of the "
-                                    "algorithmic bytes; the pass is bound by VALU issue in lock-step ray walks and by the latency of its chain of dependent launches",
+                         "frac_note": "frac / frac_algorithmic can exceed 1: SURVEY.md 8(d)'s bytes are what an implementation that fetched every record from memory would move; "
+                                      "here the tree is staged in LDS and the records come out of L2 / Infinity Cache, so the HBM roof does not bind (frac_hbm_measured is the "
+                                      "share of 8 TB/s actually used)",
+                         "valu_issue_frac": (valu_per_pass * 2.0 / (256 * 4) / 2.4e9 / (pass_ms * 1e-3)) if valu_per_pass else None,
+                         "valu_issue_note": "wave-level VALU instructions per pass (profiles/r02_<cfg>_insts.json) x 2 cycles (a wave64 instruction on a SIMD-32) / (256 CUs x 4 SIMDs x "
+                                            "2.4 GHz) / pass time: the other roof of this path, also far away",
+                         "limiter": "latency, not a throughput roof: HBM carries a tenth of its peak (the tree, bins and triangle records stay in LDS / L2 / Infinity Cache) and the "
+                                    "vector units issue about a third of theirs; a ray's walk is a chain of dependent steps (node record from LDS -> box test -> next index) on 3-4 waves "
+                                    "per SIMD, a launch lasts as long as its slowest wave, and shading gathers scattered path records",
                          "bytes_model": "SURVEY.md 8(d): 32 B/box test + 48 B/triangle test + 64 B/shaded hit + 16 B/texture sample + 36 B/pixel-pass; `achieved` prices the tests the "
                                         "timed kernels EXECUTE (bins and pruning provably skip visits the reference makes and rejects); frac_algorithmic_reference_order prices the "
                                         "reference's own un-pruned visit list and can exceed 1 for that reason",

@@ -126,7 +126,8 @@ if ins:
     tr = {k: v for k, v in ins.items() if k.startswith("gtrace") or k.startswith("trace_wave")}
     valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in tr.values())
     salu = sum(v.get("SQ_INSTS_SALU", 0.0) for v in tr.values())
-    res = {"per_kernel_in_the_timed_call": ins, "secondary_rays_in_the_timed_call": sec,
+    res = {"per_kernel_in_the_timed_call": ins, "steps_in_the_timed_call": steps, "secondary_rays_in_the_timed_call": sec,
+           "valu_instructions_per_pass": sum(v.get("SQ_INSTS_VALU", 0.0) for v in ins.values()) / steps,
            "trace_kernels_valu_instructions_per_secondary_ray": valu / sec if sec else None,
            "trace_kernels_salu_instructions_per_secondary_ray": salu / sec if sec else None,
            "note": "SQ_INSTS_VALU / SQ_INSTS_SALU are per-wave instruction counts summed over the dispatch; divided by the secondary rays the timed call traced (bench counters)"}
