@@ -71,6 +71,9 @@ struct GroupTuning {
     int round_hint[32];            // list lengths of the previous group per round (-1 = unknown): they size the launches
     int cu_count = 256;
     bool single_mesh = false, persist = true; // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
+    // a group rendered as two halves on two streams (rtwin_capi.cpp: render_passes): the first half's sky kernel takes the passes of both,
+    // the second half launches none and its resolve kernel waits for the first half's
+    int sky_passes = 0; bool no_sky = false; hipEvent_t resolve_after = nullptr;
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
     int trace_hint[32];                      // scenes with leading analytic shapes: how many rays of a round still went to the trace launch (previous group)
     bool skip_trace = false;                 // every shape is a leading analytic shape: the shading lanes do the whole query, no trace launches

@@ -2239,7 +2239,9 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     gb.capacity = (uint32_t)tune.capacity; gb.carry_on = tune.carry ? 1 : 0;
     if (!tune.counters_clean) { hipError_t e = hipMemsetAsync(gb.counters, 0, 256, stream); if (e != hipSuccess) return (int)e; }
     bool forked = false;
-    if (g.n_sky > 0) {
+    if (g.n_sky > 0 && !tune.no_sky) {
+        RtwGroupParams gs = g;
+        if (tune.sky_passes > 0) gs.n_passes = tune.sky_passes;
         hipStream_t ss = stream;
         if (tune.aux_stream) {
             forked = !tune.do_fork || (hipEventRecord(tune.fork_event, stream) == hipSuccess && hipStreamWaitEvent(tune.aux_stream, tune.fork_event, 0) == hipSuccess);
@@ -2247,7 +2249,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
         }
         int sgrid = (g.n_sky + 3) / 4;
         if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
-        hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, ss, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, g);
+        hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, ss, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, gs);
         if (forked) {
             if (tune.do_join) (void)hipEventRecord(tune.join_event, tune.aux_stream);
             else if (tune.aux_unjoined) *tune.aux_unjoined = true;
@@ -2374,6 +2376,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
             }
         }
         if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
+        if (tune.resolve_after) (void)hipStreamWaitEvent(stream, tune.resolve_after, 0);      // a pixel's passes are added in pass order
         hipLaunchKernelGGL(gresolve_kernel, dim3((unsigned)((g.n_busy + 3) / 4)), dim3(256), 0, stream, sc, (float4*)accum, (uint32_t*)argb, gb, g);
     } else if (tune.timing) {
         (void)hipEventRecord(tune.timing[1], stream); (void)hipEventRecord(tune.timing[2], stream);

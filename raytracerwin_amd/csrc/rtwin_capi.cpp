@@ -126,6 +126,14 @@ struct rtw_context {
     void* d_group_ws = nullptr;
     size_t group_ws_bytes = 0;
     bool group_clean = false;
+    // a group as two halves on two streams: the second half's stream, workspace and the events that order the halves
+    hipStream_t stream2 = nullptr;
+    void* d_group_ws2 = nullptr;
+    size_t group_ws2_bytes = 0;
+    bool group_clean2 = false;
+    hipEvent_t split_fork = nullptr, split_mid = nullptr, split_join = nullptr;
+    int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes
+    int lane = 0, lane_sky_passes = 0;        // set by rtw_render_passes around render_group
     uint32_t* h_gcounters = nullptr;    // pinned: list lengths of a finished group
     hipEvent_t gcounters_event = nullptr;
     bool gcounters_pending = false;
@@ -240,6 +248,10 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->split_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->split_mid, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->split_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault));
@@ -275,6 +287,11 @@ int rtw_context_destroy(rtw_context* ctx)
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->d_group_ws) (void)hipFree(ctx->d_group_ws);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->d_group_ws2) (void)hipFree(ctx->d_group_ws2);
+    if (ctx->split_fork) (void)hipEventDestroy(ctx->split_fork);
+    if (ctx->split_mid) (void)hipEventDestroy(ctx->split_mid);
+    if (ctx->split_join) (void)hipEventDestroy(ctx->split_join);
     if (ctx->h_gcounters) (void)hipHostFree(ctx->h_gcounters);
     if (ctx->gcounters_event) (void)hipEventDestroy(ctx->gcounters_event);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -302,6 +319,8 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         return RTW_OK;
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "group_split") == 0) { ctx->group_split = value != 0; return RTW_OK; }
+    if (std::strcmp(name, "split_min") == 0) { ctx->split_min = value < 2 ? 2 : value; return RTW_OK; }
     if (std::strcmp(name, "budget_nodes") == 0) { ctx->budget_nodes = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wide_below") == 0) { ctx->wide_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
@@ -1161,13 +1180,16 @@ static int scene_group_table(rtw_scene* scene, rtw_scene::BinSet& bs, const RtwR
 
 static int ensure_group_workspace(rtw_context* cx, size_t bytes)
 {
-    if (bytes <= cx->group_ws_bytes) return RTW_OK;
+    void*& ws = cx->lane ? cx->d_group_ws2 : cx->d_group_ws;
+    size_t& have = cx->lane ? cx->group_ws2_bytes : cx->group_ws_bytes;
+    if (bytes <= have) return RTW_OK;
     HIP_TRY(hipStreamSynchronize(cx->stream));
     if (cx->aux_stream) HIP_TRY(hipStreamSynchronize(cx->aux_stream));
-    if (cx->d_group_ws) { (void)hipFree(cx->d_group_ws); cx->d_group_ws = nullptr; cx->group_ws_bytes = 0; }
-    cx->group_clean = false;
-    HIP_TRY(hipMalloc(&cx->d_group_ws, bytes));
-    cx->group_ws_bytes = bytes;
+    if (cx->stream2) HIP_TRY(hipStreamSynchronize(cx->stream2));
+    if (ws) { (void)hipFree(ws); ws = nullptr; have = 0; }
+    (cx->lane ? cx->group_clean2 : cx->group_clean) = false;
+    HIP_TRY(hipMalloc(&ws, bytes));
+    have = bytes;
     return RTW_OK;
 }
 
@@ -1243,7 +1265,13 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
         const int kmax = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, INT32_MAX, max_bounce, carry);
         int ks = 0; while ((1 << ks) < kmax) ks++;
         if (ks < kshift) ks = kshift;
-        rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(((size_t)g.n_busy * 64 * (size_t)sub_samples) << ks, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
+        const size_t ws_bytes = rtw::group_workspace_bytes(((size_t)g.n_busy * 64 * (size_t)sub_samples) << ks, max_bounce, carry, nullptr);
+        rc = ensure_group_workspace(cx, ws_bytes); if (rc != RTW_OK) return rc;
+        if (cx->lane == 0 && cx->group_split && cx->stream2 && !use_base_color && kmax >= cx->split_min) {
+            // the second half's workspace now, not inside the first call that is long enough to be split (that call may be a timed one)
+            cx->lane = 1; rc = ensure_group_workspace(cx, ws_bytes); cx->lane = 0;
+            if (rc != RTW_OK) return rc;
+        }
     }
     rtw::GroupTuning tune;
     tune.capacity = capacity;
@@ -1252,7 +1280,9 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
     tune.gamma_thr = cx->d_gamma;
     tune.has_analytic = scene->has_analytic; tune.carry = carry;
-    tune.counters_clean = cx->group_clean;
+    tune.counters_clean = cx->lane ? cx->group_clean2 : cx->group_clean;
+    if (cx->lane == 0) tune.sky_passes = cx->lane_sky_passes;
+    else { tune.no_sky = true; tune.resolve_after = cx->split_mid; tune.aux_stream = nullptr; }
     tune.cu_count = cx->cu_count;
     if (cx->trace_stage) {      // the first mesh's upper tree levels live in the trace blocks' LDS
         for (size_t k = 0; k < scene->meshes.size(); k++)
@@ -1266,7 +1296,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.wide_ok = true;
     for (const auto& m : scene->meshes) if (m->kind == RTW_SHAPE_MESH && (m->wides.empty() || m->wide_depth > RTW_WIDE_STACK || m->wides.size() >= 65536)) tune.wide_ok = false;
     tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 5 / 2 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
-    tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
+    tune.timing = (cx->kernel_timing && cx->lane == 0) ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
     // (keyed by the launch shape WITHOUT the number of passes: the lengths are kept per pass and scaled to the group at hand, so a warm-up call of any
     // length primes a longer one)
@@ -1284,13 +1314,15 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     for (int r = 0; r < 16; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_goverflow[r]) : -1;
     for (int r = 0; r < 16; r++) tune.trace_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_gtrace[r]) : -1;
     tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();
-    cx->group_clean = false;
-    const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws, g, tune, cx->stats_enabled, cx->stream);
+    bool& clean = cx->lane ? cx->group_clean2 : cx->group_clean;
+    clean = false;
+    const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->lane ? cx->d_group_ws2 : cx->d_group_ws, g, tune, cx->stats_enabled,
+                                                              cx->lane ? cx->stream2 : cx->stream);
     if (e != hipSuccess) return hip_fail(e, "group launch");
-    cx->group_clean = true;
+    clean = true;
     cx->last_pipeline = 4;
-    cx->last_group_passes = n_passes;
-    if (!cx->gcounters_pending && g.n_busy > 0 && (!(cx->known_gkey == key) || (cx->hint_tick++ % cx->hint_period) == 0)) {
+    cx->last_group_passes = cx->lane_sky_passes > 0 ? cx->lane_sky_passes : n_passes;
+    if (cx->lane == 0 && !cx->gcounters_pending && g.n_busy > 0 && (!(cx->known_gkey == key) || (cx->hint_tick++ % cx->hint_period) == 0)) {
         if (hipMemcpyAsync(cx->h_gcounters, (char*)cx->d_group_ws + 256, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
             hipEventRecord(cx->gcounters_event, cx->stream) == hipSuccess) {
             cx->gcounters_pending = true; cx->gcounters_key = key; cx->gcounters_passes = n_passes;
@@ -1517,7 +1549,25 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
             const int k = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, n_passes - done, max_bounce, scene->texture_carry);
             const bool first = done == 0, last = done + k >= n_passes;
             cx->batch_pos = (first && last) ? 0 : (first ? 1 : (last ? 3 : 2));
-            rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);
+            if (cx->group_split && k >= cx->split_min && !use_base_color && !cx->stats_enabled && !cx->kernel_timing && cx->stream2) {
+                // The group as two halves on two streams.  Its kernels are bound by latency, not by a throughput roof: one half's short
+                // rounds and launch tails overlap the other's long ones.  Order kept: the sky kernel (second stream) takes all k passes of its pixels in a
+                // row; the second half's resolve kernel waits for the first half's, so a busy tile's passes are added in pass order.
+                const int ka = k / 2, kb = k - ka;
+                (void)hipEventRecord(cx->split_fork, cx->stream);
+                (void)hipStreamWaitEvent(cx->stream2, cx->split_fork, 0);
+                cx->lane = 0; cx->lane_sky_passes = k;
+                rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done, ka, sub_samples, seed);
+                (void)hipEventRecord(cx->split_mid, cx->stream);
+                if (rc == RTW_OK) {
+                    cx->lane = 1;
+                    rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done + ka, kb, sub_samples, seed);
+                }
+                cx->lane = 0; cx->lane_sky_passes = 0;
+                (void)hipEventRecord(cx->split_join, cx->stream2);
+                (void)hipStreamWaitEvent(cx->stream, cx->split_join, 0);
+            } else
+                rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);
             cx->batch_pos = 0;
             if (cx->aux_unjoined && (rc != RTW_OK || last)) {     // the run ends here (an error, or a last group that launched no sky kernel)
                 (void)hipEventRecord(cx->join_event, cx->aux_stream);
