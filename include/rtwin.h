@@ -102,7 +102,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   ray in the path kernel: 16 (default), 4 or 1; "path_variant": occupancy variants of the path kernel.
  *   "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms).
  *   Pass-batched pipeline (4): "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold;
- *                   "group_split" (1) a group of at least "split_min" (8) passes runs as two halves on two streams (second workspace of the same size);
+ *                   "group_split" (1) a group of at least "split_min" (8) passes and 2 x "split_paths" (400 000) paths runs as two halves on two streams
+ *                   (second workspace of the same size);
  *                   "trace_stage" (1) the trace blocks stage the first mesh's upper tree levels in LDS; "trace_persist" (1) one-mesh scenes: persistent
  *                   trace waves that refill their lanes; "wave_below" (160 000) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
  *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (384) one-mesh scenes: a ray's node visits in the

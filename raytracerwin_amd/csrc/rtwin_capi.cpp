@@ -132,7 +132,8 @@ struct rtw_context {
     size_t group_ws2_bytes = 0;
     bool group_clean2 = false;
     hipEvent_t split_fork = nullptr, split_mid = nullptr, split_join = nullptr;
-    int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes
+    int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes ...
+    int split_paths = 400000;                 // ... and each half at least this many paths (a rank's share of a small frame at 8 ranks stays whole: measured 0.0123 whole, 0.0144 ms split)
     int lane = 0, lane_sky_passes = 0;        // set by rtw_render_passes around render_group
     uint32_t* h_gcounters = nullptr;    // pinned: list lengths of a finished group
     hipEvent_t gcounters_event = nullptr;
@@ -320,6 +321,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "group_split") == 0) { ctx->group_split = value != 0; return RTW_OK; }
+    if (std::strcmp(name, "split_paths") == 0) { ctx->split_paths = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "split_min") == 0) { ctx->split_min = value < 2 ? 2 : value; return RTW_OK; }
     if (std::strcmp(name, "budget_nodes") == 0) { ctx->budget_nodes = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wide_below") == 0) { ctx->wide_below = value < 0 ? 0 : value; return RTW_OK; }
@@ -1549,7 +1551,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
             const int k = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, n_passes - done, max_bounce, scene->texture_carry);
             const bool first = done == 0, last = done + k >= n_passes;
             cx->batch_pos = (first && last) ? 0 : (first ? 1 : (last ? 3 : 2));
-            if (cx->group_split && k >= cx->split_min && !use_base_color && !cx->stats_enabled && !cx->kernel_timing && cx->stream2) {
+            if (cx->group_split && k >= cx->split_min && per_pass * (k / 2) >= cx->split_paths && !use_base_color && !cx->stats_enabled && !cx->kernel_timing && cx->stream2) {
                 // The group as two halves on two streams.  Its kernels are bound by latency, not by a throughput roof: one half's short
                 // rounds and launch tails overlap the other's long ones.  Order kept: the sky kernel (second stream) takes all k passes of its pixels in a
                 // row; the second half's resolve kernel waits for the first half's, so a busy tile's passes are added in pass order.

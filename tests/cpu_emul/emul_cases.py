@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"wave_below": 160000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0}
+DEFAULTS = {"wave_below": 160000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0, "split_min": 8, "split_paths": 400000}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 
@@ -123,6 +123,13 @@ def case_trace_variants(ctx):
     frame_case(ctx, "ray-per-lane, budget 8 + overflow", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 8)])
     frame_case(ctx, "16 lanes per ray", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wide_below", 1 << 30)])
     frame_case(ctx, "groups of 2 passes", m, 64, 48, 1, 4, 5, options=[("device_build", 0), ("group_max", 2)])
+
+
+def case_split(ctx):
+    """a group as two halves (two streams, two workspaces; forced for these small frames)"""
+    o = [("device_build", 0), ("split_min", 2), ("split_paths", 0)]
+    frame_case(ctx, "two halves: mirror", mesh("TorusKnot", SC.reflective()), 96, 54, 1, 4, 7, options=o)
+    frame_case(ctx, "two halves: SetupScene", SC.SCENES["default"](), 48, 48, 1, 4, 4, options=o, f64=True)
 
 
 def case_device_build(ctx):

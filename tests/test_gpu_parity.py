@@ -651,6 +651,40 @@ def test_k_batched_passes_equal_pass_by_pass(ctx, mesh, W, H, ns, depth, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,W,H,ns,depth,npass", [("mesh", 640, 360, 2, 4, 13), ("default_nofuzz", 400, 400, 4, 5, 8), ("quirk", 320, 180, 4, 4, 9)])
+def test_group_as_two_halves_on_two_streams(ctx, tag, W, H, ns, depth, npass):
+    """A group of passes runs as two halves on two streams (own workspaces; the sky kernel takes the passes of both halves, the second half's
+    resolve waits for the first's).  Forced here for small frames (split_min 2, split_paths 0; by default only groups of >= 8 passes with
+    >= 400 k paths per half are split): accumulator and ARGB image equal one call per pass through the single kernel, for one call and for the
+    same passes in two calls."""
+    if tag == "mesh":
+        s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5))
+    else:
+        s = multi_scene_gpu(ctx, tag)
+    ctx.set_option("pipeline", 0)
+    ref = R.Framebuffer(ctx, W, H)
+    for p in range(npass):
+        R.ThreadWorker_Render(s, ref, 0, W * H - 1, depth, None, p, ns, 77)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    ctx.set_option("split_min", 2)
+    ctx.set_option("split_paths", 0)
+    try:
+        for calls in ((npass,), (5, npass - 5)):
+            fb = R.Framebuffer(ctx, W, H)
+            p = 0
+            for n in calls:
+                s.render_passes(fb, 10, 0, 1, depth, None, p, n, ns, 77)
+                p += n
+            assert ctx.last_pass_pipeline() == 4
+            assert (bits(fb.read_float()) == bits(ra)).all() and (fb.resolve_argb() == rb).all(), calls
+            fb.close()
+    finally:
+        ctx.set_option("split_min", 8)
+        ctx.set_option("split_paths", 400000)
+
+
+@pytest.mark.gpu
 def test_groups_of_more_than_64_passes(ctx):
     """The largest groups the default policy forms (256 passes: a rank's share of a frame at 8 ranks, small frames): 200 passes of a small frame
     in one group (8 bits of a slot hold the pass), against one call per pass through the single kernel."""
