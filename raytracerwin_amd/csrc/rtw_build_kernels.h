@@ -2,9 +2,9 @@
 // derived from the tree (leaf records, the explicit-link copy, the flat hierarchy).  Included inside rtw_device.hip's anonymous namespace.
 //
 // The reference's recursion, level by level: a node is its segment [start, start + count) of the triangle order.  One wave per node:
-//   bounds      min / max over the segment's vertices (order-free, exact)
-//   mid point   sum of (v0 + v1 + v2) / 3.0f over the segment IN LIST ORDER, fp32, then / count: the wave computes 64 centroids at a time
-//               in parallel and one dependent chain of adds folds them in order (v_readlane), exactly the reference's sequence
+//   bounds      min / max over the segment's vertices (order-free, exact), through the triangles' own boxes computed once
+//   mid point   sum of (v0 + v1 + v2) / 3.0f over the segment IN LIST ORDER, fp32, then / count: 64 centroids at a time go through LDS and
+//               one dependent chain of adds per axis folds them in order, exactly the reference's sequence
 //   axis        GetLargestAxisOfBounds' `>` cascade (ties go to Z, then Y)
 //   partition   stable: left iff centroid[axis] < mid[axis] (strict), both sides keep the list order (ballot + prefix counts);
 //               a one-sided split becomes first half / second half of the current order
@@ -24,101 +24,150 @@ __device__ __forceinline__ f3 build_centroid(const float* __restrict__ pts, cons
     return mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
 }
 
-// the zero (its sign) the segment's vertices show first on axis `a`, in the order the reference expands its box: triangle by triangle, p0 p1 p2
-// (whole wave; only called when the box's bound on that axis is a zero)
-__device__ __forceinline__ float build_first_zero(const float* __restrict__ pts, const int32_t* __restrict__ idx, const int32_t* __restrict__ order, int start, int n, int a)
+// (the zero a box bound shows: +0 and -0 compare equal, the reference's sequential Expand keeps whichever it met FIRST -- triangle by triangle,
+// p0 p1 p2 -- see build_first_zero_rec)
+
+// Per-triangle data the levels read over and over, computed once: the centroid (v0 + v1 + v2) / 3.0f (the reference's operations, so its bits) and
+// the triangle's own box.  The level kernel PERMUTES these records along with the triangle order (ping-pong buffers), so that a node's segment
+// is contiguous memory: a node with 16 000 triangles is one wave, and with the three-level gather order -> index -> point of the first version
+// it spent ~2 us of latency per 64 triangles and pass (3.7 ms for unitychan's 24 levels; 1 ms with the records carried along).
+struct BuildTri { float cx, cy, cz; int32_t tri; float lox, loy, loz, pad0; float hix, hiy, hiz, pad1; };      // 48 B
+__global__ __launch_bounds__(256) void build_tri_prep_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int n, BuildTri* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const f3 c = build_centroid(pts, idx, t);
+    BuildTri r;
+    r.cx = c.x; r.cy = c.y; r.cz = c.z; r.tri = t;
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int k = 0; k < 3; k++) {
+        const int v = idx[t * 3 + k];
+        for (int a = 0; a < 3; a++) { const float x = pts[v * 3 + a]; if (x < lo[a]) lo[a] = x; if (x > hi[a]) hi[a] = x; }
+    }
+    r.lox = lo[0]; r.loy = lo[1]; r.loz = lo[2]; r.pad0 = 0.0f; r.hix = hi[0]; r.hiy = hi[1]; r.hiz = hi[2]; r.pad1 = 0.0f;
+    out[t] = r;
+}
+// the zero (its sign) the segment's vertices show first on axis `a`, in the order the reference expands its box (whole wave; only called when the
+// box's bound on that axis is a zero)
+__device__ __forceinline__ float build_first_zero_rec(const float* __restrict__ pts, const int32_t* __restrict__ idx, const BuildTri* __restrict__ recs, int start, int n, int a)
 {
     int first = 0x7FFFFFFF;
     for (int t = lane_id(); t < n && first == 0x7FFFFFFF; t += 64) {
-        const int tri = order[start + t];
+        const int tri = recs[start + t].tri;
         for (int k = 0; k < 3; k++) if (pts[idx[tri * 3 + k] * 3 + a] == 0.0f) { first = t * 3 + k; break; }
     }
     for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(first, o); first = w < first ? w : first; }
     if (first == 0x7FFFFFFF) return 0.0f;
-    return pts[idx[order[start + first / 3] * 3 + first % 3] * 3 + a];
+    return pts[idx[recs[start + first / 3].tri * 3 + first % 3] * 3 + a];
 }
 
 // one level of the recursion: the nodes of cur[0 .. *n_cur) are split, their children appended to next[]
 __global__ __launch_bounds__(256) void build_level_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx,
-                                                          const int32_t* __restrict__ order_src, int32_t* __restrict__ order_dst, int32_t* __restrict__ leaf_order,
+                                                          const BuildTri* __restrict__ src, BuildTri* __restrict__ dst, int32_t* __restrict__ leaf_order,
                                                           const BuildNode* __restrict__ cur, const uint32_t* __restrict__ n_cur, BuildNode* __restrict__ next, uint32_t* __restrict__ n_next,
                                                           RtwNode* __restrict__ nodes, int32_t* __restrict__ node_depth, uint32_t* __restrict__ level_count)
 {
+    __shared__ float cbuf[4][192];
+    float* cb = cbuf[threadIdx.x >> 6];
     const uint32_t nn = *n_cur;
     const int lane = lane_id();
     const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t w = wave0; w < nn; w += nwaves) {
         const BuildNode nd = cur[w];
         const int start = nd.start, n = nd.count;
-        // ---- bounds (RAabb::Expand over every vertex of the segment) ----
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + start);      // record t: s4[3 t] = centroid | tri, s4[3 t + 1] = lo, s4[3 t + 2] = hi
+        // ---- bounds (RAabb::Expand over every vertex of the segment = over the triangles' own boxes; min / max are order-free) ----
         float lox = FLT_MAX, loy = FLT_MAX, loz = FLT_MAX, hix = -FLT_MAX, hiy = -FLT_MAX, hiz = -FLT_MAX;
-        for (int t = lane; t < n; t += 64) {
-            const int tri = order_src[start + t];
-            for (int k = 0; k < 3; k++) {
-                const int v = idx[tri * 3 + k];
-                const float x = pts[v * 3], y = pts[v * 3 + 1], z = pts[v * 3 + 2];
-                if (x < lox) lox = x; if (x > hix) hix = x;
-                if (y < loy) loy = y; if (y > hiy) hiy = y;
-                if (z < loz) loz = z; if (z > hiz) hiz = z;
+        for (int t = lane; t < n; t += 256) {            // four independent loads in flight per lane
+            float4 lo[4], hi[4];
+            for (int u = 0; u < 4; u++) {
+                const int tt = t + 64 * u;
+                const bool in = tt < n;
+                lo[u] = in ? s4[3 * tt + 1] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+                hi[u] = in ? s4[3 * tt + 2] : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+            }
+            for (int u = 0; u < 4; u++) {
+                if (lo[u].x < lox) lox = lo[u].x; if (lo[u].y < loy) loy = lo[u].y; if (lo[u].z < loz) loz = lo[u].z;
+                if (hi[u].x > hix) hix = hi[u].x; if (hi[u].y > hiy) hiy = hi[u].y; if (hi[u].z > hiz) hiz = hi[u].z;
             }
         }
         lox = wave_min(lox); loy = wave_min(loy); loz = wave_min(loz); hix = wave_max(hix); hiy = wave_max(hiy); hiz = wave_max(hiz);
         // +0 and -0 compare equal: the reference's sequential Expand keeps whichever zero it met FIRST; the parallel reduction may hold the other
-        if (lox == 0.0f) lox = build_first_zero(pts, idx, order_src, start, n, 0);
-        if (loy == 0.0f) loy = build_first_zero(pts, idx, order_src, start, n, 1);
-        if (loz == 0.0f) loz = build_first_zero(pts, idx, order_src, start, n, 2);
-        if (hix == 0.0f) hix = build_first_zero(pts, idx, order_src, start, n, 0);
-        if (hiy == 0.0f) hiy = build_first_zero(pts, idx, order_src, start, n, 1);
-        if (hiz == 0.0f) hiz = build_first_zero(pts, idx, order_src, start, n, 2);
+        if (lox == 0.0f) lox = build_first_zero_rec(pts, idx, src, start, n, 0);
+        if (loy == 0.0f) loy = build_first_zero_rec(pts, idx, src, start, n, 1);
+        if (loz == 0.0f) loz = build_first_zero_rec(pts, idx, src, start, n, 2);
+        if (hix == 0.0f) hix = build_first_zero_rec(pts, idx, src, start, n, 0);
+        if (hiy == 0.0f) hiy = build_first_zero_rec(pts, idx, src, start, n, 1);
+        if (hiz == 0.0f) hiz = build_first_zero_rec(pts, idx, src, start, n, 2);
         RtwNode rec;
         rec.min_x = lox; rec.min_y = loy; rec.min_z = loz; rec.max_x = hix; rec.max_y = hiy; rec.max_z = hiz;
         rec.skip = nd.index + 2 * n - 1;
         if (n == 1) {                    // a leaf: its slot in leaf order is its place in the triangle order
-            const int tri = order_src[start];
+            const int tri = __float_as_int(s4[0].w);
             rec.tri = start;
             if (lane == 0) { nodes[nd.index] = rec; node_depth[nd.index] = nd.depth; leaf_order[start] = tri; }
             continue;
         }
         rec.tri = -1;
-        // ---- NodeMidPoint: the centroids summed in list order (one chain of dependent adds), then / NumTriangles ----
-        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        // ---- NodeMidPoint: the centroids summed in list order (one chain of dependent adds), then / NumTriangles; the next 64 centroids
+        // are fetched while the chain folds the current ones ----
+        // (lanes 0, 1, 2 fold x, y, z: one LDS read and one add per element for the three axes together, instead of three v_readlane + add pairs)
+        float m = 0.0f;
+        float4 cn = lane < n ? s4[3 * lane] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int t0 = 0; t0 < n; t0 += 64) {
             const int cnt = n - t0 < 64 ? n - t0 : 64;
-            f3 c = mk(0, 0, 0);
-            if (lane < cnt) c = build_centroid(pts, idx, order_src[start + t0 + lane]);
-            for (int j = 0; j < cnt; j++) { mx = mx + readlane_f(c.x, j); my = my + readlane_f(c.y, j); mz = mz + readlane_f(c.z, j); }
+            const float4 c = cn;
+            const int tn = t0 + 64 + lane;
+            cn = tn < n ? s4[3 * tn] : make_float4(0.f, 0.f, 0.f, 0.f);
+            cb[lane * 3] = c.x; cb[lane * 3 + 1] = c.y; cb[lane * 3 + 2] = c.z;
+            wave_lds_sync();
+            if (lane < 3) for (int j = 0; j < cnt; j++) m = m + cb[j * 3 + lane];
+            wave_lds_sync();
         }
         const float fn = (float)n;
-        mx = mx / fn; my = my / fn; mz = mz / fn;
+        const float mx = readlane_f(m, 0) / fn, my = readlane_f(m, 1) / fn, mz = readlane_f(m, 2) / fn;
         // ---- GetLargestAxisOfBounds ----
         const float sx = hix - lox, sy = hiy - loy, sz = hiz - loz;
         const int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);
         const float cut = axis == 0 ? mx : (axis == 1 ? my : mz);
         // ---- how many go left ----
         int n_left = 0;
-        for (int t0 = 0; t0 < n; t0 += 64) {
-            bool left = false;
-            if (t0 + lane < n) { const f3 c = build_centroid(pts, idx, order_src[start + t0 + lane]); const float v = axis == 0 ? c.x : (axis == 1 ? c.y : c.z); left = v < cut; }
-            n_left += (int)__popcll(__ballot(left));
+        for (int t0 = 0; t0 < n; t0 += 256) {
+            float4 c[4];
+            for (int u = 0; u < 4; u++) { const int tt = t0 + 64 * u + lane; c[u] = tt < n ? s4[3 * tt] : make_float4(0.f, 0.f, 0.f, 0.f); }
+            for (int u = 0; u < 4; u++) {
+                const int tt = t0 + 64 * u + lane;
+                const float v = axis == 0 ? c[u].x : (axis == 1 ? c[u].y : c[u].z);
+                n_left += (int)__popcll(__ballot(tt < n && v < cut));
+            }
         }
         const bool one_sided = n_left == 0 || n_left == n;
         if (one_sided) n_left = n / 2;
-        // ---- the two sides, each in list order ----
+        // ---- the two sides, each in list order: the records move with their triangles ----
+        float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + start);
         int done_l = 0, done_r = 0;
-        for (int t0 = 0; t0 < n; t0 += 64) {
-            const bool mine = t0 + lane < n;
-            const int tri = mine ? order_src[start + t0 + lane] : 0;
-            bool left = false;
-            if (mine) {
-                if (one_sided) left = t0 + lane < n_left;
-                else { const f3 c = build_centroid(pts, idx, tri); const float v = axis == 0 ? c.x : (axis == 1 ? c.y : c.z); left = v < cut; }
+        for (int t0 = 0; t0 < n; t0 += 128) {
+            float4 r0[2], r1[2], r2[2];
+            for (int u = 0; u < 2; u++) {
+                const int tt = t0 + 64 * u + lane;
+                if (tt < n) { r0[u] = s4[3 * tt]; r1[u] = s4[3 * tt + 1]; r2[u] = s4[3 * tt + 2]; }
+                else { r0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r1[u] = r0[u]; r2[u] = r0[u]; }
             }
-            const unsigned long long ml = __ballot(mine && left), mr = __ballot(mine && !left);
-            if (mine) {
-                if (left) order_dst[start + done_l + mbcnt(ml)] = tri;
-                else order_dst[start + n_left + done_r + mbcnt(mr)] = tri;
+            for (int u = 0; u < 2; u++) {
+                const int tt = t0 + 64 * u + lane;
+                const bool mine = tt < n;
+                bool left = false;
+                if (mine) {
+                    if (one_sided) left = tt < n_left;
+                    else { const float v = axis == 0 ? r0[u].x : (axis == 1 ? r0[u].y : r0[u].z); left = v < cut; }
+                }
+                const unsigned long long ml = __ballot(mine && left), mr = __ballot(mine && !left);
+                if (mine) {
+                    const int at = left ? done_l + mbcnt(ml) : n_left + done_r + mbcnt(mr);
+                    d4[3 * at] = r0[u]; d4[3 * at + 1] = r1[u]; d4[3 * at + 2] = r2[u];
+                }
+                done_l += (int)__popcll(ml); done_r += (int)__popcll(mr);
             }
-            done_l += (int)__popcll(ml); done_r += (int)__popcll(mr);
         }
         if (lane == 0) {
             nodes[nd.index] = rec; node_depth[nd.index] = nd.depth;
@@ -325,12 +374,30 @@ __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ 
     for (int i = lo; i < hi; i++) { off[i] = t; t += counts[i]; counts[i] = 0u; }
 }
 
-// every bin's entries ascending (node index = preorder); lists are short: a lane per bin, insertion sort
-__global__ void bins_sort_kernel(const uint32_t* __restrict__ off, uint32_t* __restrict__ ent, int n_bins)
+// every bin's entries ascending (node index = preorder).  A wave per bin: the list goes to LDS and every entry's place is its rank -- the count
+// of smaller entries (a bin holds a node once, so ranks are distinct).  (A lane per bin with an insertion sort in global memory took 2.2 ms on
+// unitychan's bins, whose longest list has 197 entries: the whole launch waited for that lane.)  Lists longer than the LDS row keep the slow way.
+#define RTW_BINS_SORT_ROW 1024
+__global__ __launch_bounds__(256) void bins_sort_kernel(const uint32_t* __restrict__ off, uint32_t* __restrict__ ent, int n_bins)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t rows[4][RTW_BINS_SORT_ROW];
+    const int b = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = lane_id();
     if (b >= n_bins) return;
-    const uint32_t lo = off[b], hi = off[b + 1];
+    const uint32_t lo = off[b], hi = off[b + 1], n = hi - lo;
+    if (n < 2u) return;
+    if (n <= (uint32_t)RTW_BINS_SORT_ROW) {
+        uint32_t* row = rows[threadIdx.x >> 6];
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64u) row[i] = ent[lo + i];
+        wave_lds_sync();
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
+            const uint32_t v = row[i];
+            uint32_t rank = 0u;
+            for (uint32_t j = 0; j < n; j++) rank += row[j] < v ? 1u : 0u;
+            ent[lo + rank] = v;
+        }
+        return;
+    }
+    if (lane != 0) return;
     for (uint32_t i = lo + 1; i < hi; i++) {
         const uint32_t v = ent[i];
         uint32_t j = i;

@@ -6,6 +6,7 @@
 // this path; the hot loop is a stack-free walk over 32-byte nodes (one ray per lane).
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -2391,7 +2392,6 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
 
 // ---- KdNode::Build + derived layouts on the device (rtw_build_kernels.h) ------------------------------------------------------
 namespace {
-__global__ void build_iota_kernel(int32_t* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
 struct TempBufs {
     std::vector<void*> v;
     ~TempBufs() { for (void* p : v) (void)hipFree(p); }
@@ -2400,16 +2400,20 @@ struct TempBufs {
 }  // namespace
 
 #define RTW_HIP_OK(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define BUILD_MARK(what) do { if (btrace) { (void)hipStreamSynchronize(stream); timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); const double t_ = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; fprintf(stderr, "    build: %-20s %.3f ms\n", what, t_ - bt_last); bt_last = t_; } } while (0)
 int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* out, hipStream_t stream)
 {
+    static const bool btrace = std::getenv("RTW_COMMIT_TRACE") != nullptr;
+    double bt_last = 0; { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); bt_last = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     const int n = in.n_tris, n_nodes = 2 * n - 1;
     if (n <= 0) return (int)hipErrorInvalidValue;
     TempBufs tmp;
-    float *d_pts, *d_tcs, *d_nrm; int32_t *d_ip, *d_it, *d_in, *d_mat, *d_ord[2], *d_leaf, *d_depth, *d_place, *d_ntop;
+    BUILD_MARK("entry");
+    float *d_pts, *d_tcs, *d_nrm; int32_t *d_ip, *d_it, *d_in, *d_mat, *d_leaf, *d_depth, *d_place, *d_ntop; BuildTri* d_rec[2];
     BuildNode* d_lvl[2]; uint32_t* d_cnt;      // d_cnt[0..1]: node counts of the two level lists, d_cnt[2..65]: nodes per depth
     RTW_HIP_OK(tmp.get(&d_pts, (size_t)in.n_points * 3)); RTW_HIP_OK(tmp.get(&d_tcs, (size_t)in.n_texcoords * 3)); RTW_HIP_OK(tmp.get(&d_nrm, (size_t)in.n_normals * 3));
     RTW_HIP_OK(tmp.get(&d_ip, (size_t)n * 3)); RTW_HIP_OK(tmp.get(&d_it, (size_t)n * 3)); RTW_HIP_OK(tmp.get(&d_in, (size_t)n * 3)); RTW_HIP_OK(tmp.get(&d_mat, (size_t)n));
-    RTW_HIP_OK(tmp.get(&d_ord[0], (size_t)n)); RTW_HIP_OK(tmp.get(&d_ord[1], (size_t)n)); RTW_HIP_OK(tmp.get(&d_leaf, (size_t)n));
+    RTW_HIP_OK(tmp.get(&d_rec[0], (size_t)n)); RTW_HIP_OK(tmp.get(&d_rec[1], (size_t)n)); RTW_HIP_OK(tmp.get(&d_leaf, (size_t)n));
     RTW_HIP_OK(tmp.get(&d_depth, (size_t)n_nodes)); RTW_HIP_OK(tmp.get(&d_place, (size_t)n_nodes + 1)); RTW_HIP_OK(tmp.get(&d_ntop, 1));
     RTW_HIP_OK(tmp.get(&d_lvl[0], (size_t)n + 2)); RTW_HIP_OK(tmp.get(&d_lvl[1], (size_t)n + 2)); RTW_HIP_OK(tmp.get(&d_cnt, 66));
     RTW_HIP_OK(hipMemcpyAsync(d_pts, in.points, (size_t)in.n_points * 12, hipMemcpyHostToDevice, stream));
@@ -2419,6 +2423,7 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
     RTW_HIP_OK(hipMemcpyAsync(d_it, in.idx_t, (size_t)n * 12, hipMemcpyHostToDevice, stream));
     RTW_HIP_OK(hipMemcpyAsync(d_in, in.idx_n, (size_t)n * 12, hipMemcpyHostToDevice, stream));
     RTW_HIP_OK(hipMemcpyAsync(d_mat, in.tri_material, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    BUILD_MARK("temps + uploads");
     // outputs (owned by the caller afterwards)
     DeviceBuildOut o; std::memset(&o, 0, sizeof o);
     o.n_nodes = n_nodes;
@@ -2435,8 +2440,9 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
             cnt = (cnt + 15) / 16;
         }
     }
+    BUILD_MARK("output buffers");
     // the recursion, level by level
-    hipLaunchKernelGGL(build_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_ord[0], n);
+    hipLaunchKernelGGL(build_tri_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_pts, d_ip, n, d_rec[0]);      // centroid + own box of every triangle, once
     RTW_HIP_OK(hipMemsetAsync(d_cnt, 0, 66 * 4, stream));
     {
         const BuildNode root = { 0, n, 0, 0 };
@@ -2455,7 +2461,7 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
             unsigned blocks = (unsigned)(((long long)(n < (1 << level) || level > 20 ? n : (1 << level)) + 3) / 4);
             if (blocks > 8192u) blocks = 8192u;
             if (blocks < 1u) blocks = 1u;
-            hipLaunchKernelGGL(build_level_kernel, dim3(blocks), dim3(256), 0, stream, d_pts, d_ip, d_ord[c], d_ord[1 - c], d_leaf, d_lvl[c], &d_cnt[c], d_lvl[1 - c], &d_cnt[1 - c],
+            hipLaunchKernelGGL(build_level_kernel, dim3(blocks), dim3(256), 0, stream, d_pts, d_ip, d_rec[c], d_rec[1 - c], d_leaf, d_lvl[c], &d_cnt[c], d_lvl[1 - c], &d_cnt[1 - c],
                                o.nodes, d_depth, &d_cnt[2]);
         }
         uint32_t left = 0;
@@ -2464,6 +2470,7 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
         if (left == 0u) break;
         if (level > 4 * n + 64) return (int)hipErrorUnknown;        // cannot happen: every level splits every segment
     }
+    BUILD_MARK("levels");
     // depth statistics -> how many levels fit the LDS budget of the trace kernels (the host build's rule)
     uint32_t per_level[64];
     RTW_HIP_OK(hipMemcpyAsync(per_level, &d_cnt[2], sizeof per_level, hipMemcpyDeviceToHost, stream));
@@ -2482,6 +2489,7 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
     RTW_HIP_OK(hipMemcpyAsync(&ntop, d_ntop, 4, hipMemcpyDeviceToHost, stream));
     RTW_HIP_OK(hipStreamSynchronize(stream));
     RTW_HIP_OK(hipGetLastError());
+    BUILD_MARK("derived layouts");
     o.tnodes_top = D < 0 ? 0 : ntop;
     *out = o;
     return 0;
@@ -2515,7 +2523,7 @@ int device_build_bins(const RtwNode* d_nodes, const RtwTri* d_tris, int n_nodes,
     uint32_t* d_ent = nullptr;
     RTW_HIP_OK(hipMalloc((void**)&d_ent, ((size_t)total + 1) * 4));
     hipLaunchKernelGGL(bins_pass_kernel<1>, dim3(nb), dim3(256), 0, stream, d_nodes, d_tris, n_nodes, g, d_counts, (const uint32_t*)d_off, d_ent, d_flag);
-    hipLaunchKernelGGL(bins_sort_kernel, dim3((unsigned)((n_bins + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)d_off, d_ent, n_bins);
+    hipLaunchKernelGGL(bins_sort_kernel, dim3((unsigned)((n_bins + 3) / 4)), dim3(256), 0, stream, (const uint32_t*)d_off, d_ent, n_bins);       // a wave per bin
     RTW_HIP_OK(hipStreamSynchronize(stream));
     RTW_HIP_OK(hipGetLastError());
     *off_out = d_off; *ent_out = d_ent; *has_bins = 1;

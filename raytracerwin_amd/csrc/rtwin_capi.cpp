@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <climits>
 #include <cstddef>
 #include <cstdio>
@@ -618,8 +619,12 @@ int rtw_scene_set_prune(rtw_scene* scene, int enabled)
     return RTW_OK;
 }
 
+static double commit_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define COMMIT_MARK(what) do { if (trace) { (void)hipStreamSynchronize(scene->ctx->stream); const double t_ = commit_now(); std::fprintf(stderr, "  commit: %-28s %.3f ms\n", what, t_ - t_last); t_last = t_; } } while (0)
 int rtw_scene_commit(rtw_scene* scene)
 {
+    static const bool trace = std::getenv("RTW_COMMIT_TRACE") != nullptr;
+    double t_last = commit_now();
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
     if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
     if (!scene->ctx) {      // host-only scene: build the flattened trees for inspection, nothing to upload
@@ -656,6 +661,7 @@ int rtw_scene_commit(rtw_scene* scene)
             rtw::DeviceBuildOut o;
             const hipError_t be = (hipError_t)rtw::device_build_mesh(in, RTW_TNODES_TOP_BUDGET, &o, scene->ctx->stream);
             if (be != hipSuccess) return hip_fail(be, "device tree build");
+            COMMIT_MARK("device_build_mesh");
             scene->allocs.push_back(o.nodes); scene->allocs.push_back(o.tnodes); scene->allocs.push_back(o.tris); scene->allocs.push_back(o.shade);
             for (int l = 0; l < 3; l++) scene->allocs.push_back(o.flat[l]);
             m.nodes.resize((size_t)o.n_nodes); m.tnodes.resize((size_t)o.n_nodes); m.tris.resize((size_t)in.n_tris); m.shade.resize((size_t)in.n_tris);
@@ -673,10 +679,13 @@ int rtw_scene_commit(rtw_scene* scene)
             d.nodes = o.nodes; d.tnodes = o.tnodes; d.tnodes_top = o.tnodes_top; d.tris = o.tris; d.shade = o.shade;
             scene->d_nodes_of.resize(scene->meshes.size(), nullptr); scene->d_tris_of.resize(scene->meshes.size(), nullptr);
             scene->d_nodes_of[s] = o.nodes; scene->d_tris_of[s] = o.tris;
+            COMMIT_MARK("read back");
         } else {
             rtw::build_tree(m);
+            COMMIT_MARK("host build_tree");
         }
         rtw::build_quads(m);
+        COMMIT_MARK("host build_quads");
         if (!on_device && (rc = upload(scene, m.nodes, &d.nodes)) != RTW_OK) return rc;
         if (m.quad_depth <= RTW_QUAD_STACK) {
             if ((rc = upload(scene, m.quads, &d.quads)) != RTW_OK) return rc;
@@ -698,6 +707,7 @@ int rtw_scene_commit(rtw_scene* scene)
             if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
             if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
         }
+        COMMIT_MARK("layouts + uploads");
         std::vector<uint32_t> atlas;
         for (size_t t = 0; t < m.textures.size() && t < RTW_DEV_MAX_TEXTURES; t++) {
             const rtw::HostTexture& tx = m.textures[t];
@@ -707,6 +717,7 @@ int rtw_scene_commit(rtw_scene* scene)
             atlas.insert(atlas.end(), tx.rgba8.begin(), tx.rgba8.end());
         }
         if ((rc = upload(scene, atlas, &d.texels)) != RTW_OK) return rc;
+        COMMIT_MARK("texture atlas");
         for (int k = 0; k < 3; k++) { d.bmin[k] = m.bmin[k]; d.bmax[k] = m.bmax[k]; }
         d.n_nodes = (int)m.nodes.size(); d.n_tris = (int)m.tris.size();
         d.n_textures = m.n_textures_slots;
