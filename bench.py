@@ -431,7 +431,7 @@ def main():
         fb2.close()
         # ---- host vs device construction of the tree / layouts / screen bins (untimed; two fresh scenes)
         build_ms = {}
-        for label, dev_build in (("device", 1), ("host", 0)):
+        for label, dev_build in (("device", 1), ("host", 0), ("device", 1), ("host", 0)):       # twice each, alternating; the faster run of each is kept
             ctx.set_option("device_build", dev_build)
             sc2 = R.RayTracerScene(ctx)
             if kind == "setup":
@@ -444,7 +444,8 @@ def main():
             t1 = time.perf_counter()
             sc2.mesh_bins(W, H, 16, 4, shape=sc2.n_shapes - 1)
             t2 = time.perf_counter()
-            build_ms[label] = {"commit_ms": (t1 - t0) * 1e3, "screen_bins_ms": (t2 - t1) * 1e3}
+            got = {"commit_ms": (t1 - t0) * 1e3, "screen_bins_ms": (t2 - t1) * 1e3}
+            build_ms[label] = got if label not in build_ms else {k: min(got[k], build_ms[label][k]) for k in got}
             sc2.close()
         ctx.set_option("device_build", 1)
 
@@ -498,7 +499,7 @@ def main():
             "tree_and_bins_build_ms": build_ms,
             "host_setup_note": "scene_commit_ms = tree build (on the device by default, the reference's split decisions) + derived layouts + upload / read-back; bins_and_tables_build_ms = "
                                "first render call of this frame shape minus the second (screen bins on the device, busy / sky tile lists and job table on the host); "
-                               "tree_and_bins_build_ms times both constructions, device and host, on fresh scenes; none of it is in the timed region",
+                               "tree_and_bins_build_ms times both constructions, device and host, on fresh scenes (two runs each, alternating, the faster kept; commit_ms includes the texture atlas upload, the same either way); none of it is in the timed region",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "frac_algorithmic": achieved / HBM_PEAK_GBS,

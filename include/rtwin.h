@@ -105,7 +105,7 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   "group_split" (1) a group of at least "split_min" (8) passes and 2 x "split_paths" (400 000) paths runs as two halves on two streams
  *                   (second workspace of the same size);
  *                   "trace_stage" (1) the trace blocks stage the first mesh's upper tree levels in LDS; "trace_persist" (1) one-mesh scenes: persistent
- *                   trace waves that refill their lanes; "wave_below" (160 000) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
+ *                   trace waves that refill their lanes; "wave_below" (80 000; x 5 for trees of more than 4 096 nodes) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
  *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (384) one-mesh scenes: a ray's node visits in the
  *                   ray-per-lane kernel before it goes to the wave-per-ray one (a rare ray that walks a thousand nodes kept its whole wave waiting: the
  *                   slowest C2 call in 24 went from 1.17 to 0.98 ms), for trees with more than "budget_nodes" (0) nodes; "device_build" (1) tree, layouts and screen bins built on the device. */

@@ -152,7 +152,7 @@ struct rtw_context {
     int group_paths = 16 << 20;         // passes are grouped until a launch holds about this many paths ...
     int group_max = 256;                // ... and at most this many passes (a power of two)
     int wide_below = 0;                 // trace rounds with at least wave_below and fewer than this many rays run sixteen lanes per ray on the 16-wide tree (0: never)
-    int wave_below = 160000;            // trace rounds with fewer rays than this (previous group's count) run a wave per ray instead of a ray per lane
+    int wave_below = 80000;             // a trace round with fewer rays (x 5 for trees of more than 4096 nodes) runs a wave per ray (measured with groups as two halves: C2 -3 % against 160 000; big trees keep 400 000)
     int device_build = 1;               // rtw_scene_commit builds the tree (KdNode::Build's decisions) and the layouts derived from it on the device (0: on the host)
     int trace_persist = 1;              // one-mesh scenes: persistent trace waves that refill their lanes
     int trace_stage = 1;                // the ray-per-lane trace kernel stages the first mesh's upper tree levels in LDS (1024-thread blocks)
@@ -1308,7 +1308,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.wide_below = cx->wide_below;
     tune.wide_ok = true;
     for (const auto& m : scene->meshes) if (m->kind == RTW_SHAPE_MESH && (m->wides.empty() || m->wide_depth > RTW_WIDE_STACK || m->wides.size() >= 65536)) tune.wide_ok = false;
-    tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 5 / 2 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
+    tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 5 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
     tune.timing = (cx->kernel_timing && cx->lane == 0) ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
     // (keyed by the launch shape WITHOUT the number of passes: the lengths are kept per pass and scaled to the group at hand, so a warm-up call of any

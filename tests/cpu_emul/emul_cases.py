@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"wave_below": 160000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0, "split_min": 8, "split_paths": 400000}
+DEFAULTS = {"wave_below": 80000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0, "split_min": 8, "split_paths": 400000}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 

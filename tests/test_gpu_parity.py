@@ -747,7 +747,7 @@ def test_pass_batched_trace_variants_agree(ctx, mesh, ns, depth):
             else:
                 assert (bits(out[0]) == bits(ref[0])).all() and (out[1] == ref[1]).all(), (persist, stage, below, budget)
     finally:
-        for k, v in (("trace_persist", 1), ("trace_stage", 1), ("wave_below", 160000), ("visit_budget", 384)):
+        for k, v in (("trace_persist", 1), ("trace_stage", 1), ("wave_below", 80000), ("visit_budget", 384)):
             ctx.set_option(k, v)
     ctx.set_option("pipeline", 0)
     a0, b0 = R.Framebuffer(ctx, W, H), None

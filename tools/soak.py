@@ -71,7 +71,7 @@ def material(rng, depth=0):
 
 
 DEFAULTS = dict(pipeline=4, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1,
-                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=160000, visit_budget=384)
+                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=80000, visit_budget=384)
 
 
 def run(seed_arg, cases, ctx=None, log=print):
