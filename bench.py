@@ -252,11 +252,21 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    # REHEARSAL of the N > 1 code path on a box with ONE GPU (tools/rehearse_multirank.sh): RTW_BENCH_REHEARSE=1 puts every rank on GPU 0, with
+    # gloo for the process group and the loopback stand-in for librccl under rtw_gather_rows (RCCL refuses two ranks on one device).  The line it
+    # prints says so in `rehearsal`; its throughput means nothing (the ranks share one GPU) -- what it checks is that every rank gets through
+    # the bootstrap, the K passes of its tasks, the gather and the verification against the one-GPU replay.
+    rehearse = os.environ.get("RTW_BENCH_REHEARSE", "") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     mesh, W, H, spp, depth, kind = CONFIGS[args.config]
     if args.depth > 0:
@@ -525,6 +535,8 @@ def main():
                          "algorithmic_bytes_per_pass_reference_order": alg_ref,
                          "counters_per_pass_reference_order": st_ref, "counters_per_pass_as_run": st_run_pass},
         }
+        if rehearse:
+            result["rehearsal"] = "RTW_BENCH_REHEARSE=1: all %d ranks on GPU 0, gloo process group, loopback transport under rtw_gather_rows -- a check of the code path, not a measurement" % world
         if world > 1:
             result["gather_ms"] = gather_ms
             result["gather"] = gather_kind + ("; ARGB only" if (not args.gather_accum) else "; accumulator + ARGB")

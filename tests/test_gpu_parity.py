@@ -942,3 +942,20 @@ def test_gather_plan_between_ranks_sharing_one_gpu(ctx, tmp_path, world, mode):
         row_task = (np.arange(W * H) // W) // ROWS
         mine = (row_task % world) == 0
         assert (bits(got["accum"][mine]) == bits(want_accum[mine])).all() and (got["accum"][~mine] == 0).all()
+
+
+@pytest.mark.gpu
+def test_bench_multirank_code_path_rehearsed_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank under torch.distributed.run), rehearsed on this one-GPU box: every rank on
+    GPU 0, gloo for the process group, the loopback stand-in for librccl under rtw_gather_rows (tools/rehearse_multirank.sh).  The line must come out
+    with the gathered image verified against the one-GPU replay; RCCL's own part is the one thing this cannot show."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multirank.sh"), "2", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and "rehearsal" in d
+    assert d["gather_verified_bit_identical_to_1gpu"] is True
+    assert d["gather"].startswith("rtw_gather_rows")
