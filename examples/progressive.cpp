@@ -1,10 +1,14 @@
 // progressive.cpp -- the reference's render thread (UpdateBitmapPixels, Src/RayTracerProgram.cpp:270-422) on the GPU: preview pass, N accumulated
 // passes with the reference's progress line (also the window title), Output_<spp>spp_<date>.png in SavedImages/, and the frames presented
 // to a RenderWindow-shaped sink (Src/Linux/RenderWindow_X11.h:11-30) that counts them here.
-//   usage: progressive MESH.obj WIDTH HEIGHT PASSES MAXBOUNCE [OUT.argb [PASSES_PER_UPDATE]]
+//   usage: progressive MESH.obj WIDTH HEIGHT PASSES MAXBOUNCE [OUT.argb [PASSES_PER_UPDATE [RANK WORLD IDFILE]]]
+// Several ranks (one process per GPU): rank 0 makes the RCCL id and leaves it in IDFILE, the others read it; every rank renders its 10-row tasks,
+// rank 0 gathers before every present and before it saves the image.
 // Build: g++ -std=c++11 -Iinclude examples/progressive.cpp -Lraytracerwin_amd -lrtwin -Wl,-rpath,$PWD/raytracerwin_amd
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "RayTracerWin.hpp"
 
@@ -21,7 +25,7 @@ static void OnTitle(void* user, const char*) { ((Seen*)user)->titles++; }
 
 int main(int argc, char** argv)
 {
-    if (argc < 6) { std::fprintf(stderr, "usage: %s MESH.obj W H PASSES MAXBOUNCE [OUT.argb [PASSES_PER_UPDATE]]\n", argv[0]); return 2; }
+    if (argc < 6) { std::fprintf(stderr, "usage: %s MESH.obj W H PASSES MAXBOUNCE [OUT.argb [PASSES_PER_UPDATE [RANK WORLD IDFILE]]]\n", argv[0]); return 2; }
     const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), TotalSamplesNum = std::atoi(argv[4]), MaxBounceTimes = std::atoi(argv[5]);
     try {
         RtwDevice Device(0);
@@ -38,7 +42,28 @@ int main(int argc, char** argv)
         RtwProgressive Run;
         Run.TotalSamplesNum = TotalSamplesNum; Run.MaxBounceTimes = MaxBounceTimes; Run.Window = &Window;
         Run.PassesPerUpdate = argc > 7 ? std::atoi(argv[7]) : 1;
+        rtw_comm* Comm = nullptr;
+        if (argc > 10 && std::atoi(argv[9]) > 1) {      // several ranks: the id travels through a file (any channel will do: MPI, a socket ...)
+            Run.Rank = std::atoi(argv[8]); Run.World = std::atoi(argv[9]);
+            uint8_t Id[RTW_COMM_ID_BYTES];
+            const std::string IdFile = argv[10];
+            if (Run.Rank == 0) {
+                RtwCheck(rtw_comm_unique_id(Id));
+                FILE* f = std::fopen((IdFile + ".tmp").c_str(), "wb"); std::fwrite(Id, 1, sizeof Id, f); std::fclose(f);
+                std::rename((IdFile + ".tmp").c_str(), IdFile.c_str());
+            } else {
+                FILE* f = nullptr;
+                for (int tries = 0; tries < 6000 && !(f = std::fopen(IdFile.c_str(), "rb")); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                if (!f || std::fread(Id, 1, sizeof Id, f) != sizeof Id) { std::fprintf(stderr, "rank %d: no communicator id in %s\n", Run.Rank, IdFile.c_str()); return 3; }
+                std::fclose(f);
+            }
+            RtwCheck(rtw_comm_create(Device.Get(), Id, Run.Rank, Run.World, &Comm));
+            Run.Comm = Comm;
+            if (Run.Rank != 0) { Run.Window = nullptr; Run.Quiet = true; }
+        }
         const std::string Saved = UpdateBitmapPixels(Device, Scene, Buffer, Run);
+        if (Comm) RtwCheck(rtw_comm_destroy(Comm));
+        if (Run.Rank != 0) return 0;
         Window.RunWindowLoop();
         if (argc > 6) {
             const std::vector<Pixel> bitcolor = Buffer.bitcolor();

@@ -393,7 +393,8 @@ inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, 
         Show(Line);
         if (Run.bQuit && *Run.bQuit) break;
     }
-    if (Run.World > 1 && Run.Comm && !Run.Window) RtwCheck(rtw_gather_rows(Run.Comm, Buffer.Get(), TaskRows, Run.ArgbOnlyGather ? RTW_GATHER_ARGB : RTW_GATHER_ALL));
+    // (every update's Show() has gathered, the last one after the last pass: rank 0 holds the whole image here.  The gather is a collective of the
+    // ranks: it must never depend on something only one rank has, such as a window)
     Device.Synchronize();
     if (Root && !Run.Quiet) std::printf("Finished rendering image.\n");
     if (!Root || Rendered == 0) return std::string();

@@ -134,6 +134,54 @@ def test_update_bitmap_pixels_loop_names_its_png_and_accumulates_like_pass_by_pa
         assert (im[..., 0].ravel() == (cpp >> 16) & 255).all() and (im[..., 1].ravel() == (cpp >> 8) & 255).all() and (im[..., 2].ravel() == cpp & 255).all()
 
 
+@pytest.mark.gpu
+def test_update_bitmap_pixels_on_three_ranks_equals_the_one_rank_image(tmp_path):
+    """The facade's UpdateBitmapPixels with Rank / World / Comm: three processes of examples/progressive.cpp, each rendering its
+    10-row tasks, rank 0 gathering through rtw_gather_rows before every present and before it saves the PNG.  On this one-GPU box the three ranks share
+    the GPU, so the transport under the gather is the loopback stand-in for librccl (tests/support/loopback_rccl.cpp, loaded through
+    RTW_RCCL_LIBRARY); the id still travels from rank 0 to the others as it would with RCCL (a file).  Rank 0's final image, the frames its window
+    was shown and its PNG equal the oracle's image of the whole frame."""
+    import re
+    from oracle import oracle as O
+    exe = build_example(tmp_path, "progressive")
+    lib = str(tmp_path / "libloopback_rccl.so")
+    subprocess.check_call(["g++", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "support", "loopback_rccl.cpp"),
+                           "-o", lib, "-L/opt/rocm/lib", "-lamdhip64"])
+    (tmp_path / "SavedImages").mkdir()
+    (tmp_path / "SavedImages" / "Output.txt").write_text("")
+    run_dir = tmp_path / "Build"
+    run_dir.mkdir()
+    W, H, N, world = 200, 117, 5, 3             # 12 tasks, the last one ragged
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("TorusKnot.obj"))
+    os_.set_material(sh, [(O.MAT_DIFFUSE, (1, 1, 1), 0, 0, 0)])
+    ofb = O.Framebuffer(W, H)
+    for p in range(N):
+        os_.render_pass_pool(ofb, 4, False, p, 4, 12345, threads=0, task_rows=10)
+    want = ofb.read()[1]
+    env = dict(os.environ, RTW_RCCL_LIBRARY=lib, RTW_LOOPBACK_DIR=str(tmp_path))
+    raw = str(tmp_path / "rank0.argb")
+    procs = [subprocess.Popen([exe, asset("TorusKnot.obj"), str(W), str(H), str(N), "4", raw if r == 0 else str(tmp_path / ("rank%d.argb" % r)), "2",
+                               str(r), str(world), str(tmp_path / "comm.id")], cwd=str(run_dir), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(("", "timeout"))
+    assert [p.returncode for p in procs] == [0] * world, outs
+    got = np.fromfile(raw, np.uint32)
+    assert (got == want).all()
+    assert re.search(r"last frame equals the final image", outs[0][0]), outs[0][0]
+    pngs = [f for f in os.listdir(str(tmp_path / "SavedImages")) if f.endswith(".png")]
+    assert len(pngs) == 1                           # rank 0 alone saves
+    from PIL import Image
+    im = np.asarray(Image.open(os.path.join(str(tmp_path / "SavedImages"), pngs[0])))
+    assert (im[..., 0].ravel() == (got >> 16) & 255).all() and (im[..., 2].ravel() == got & 255).all()
+
+
 def test_default_scene_example_compiles_and_refuses_to_run_without_a_gpu(tmp_path):
     import torch
     exe = build_example(tmp_path, "default_scene")
