@@ -71,7 +71,7 @@ def material(rng, depth=0):
 
 
 DEFAULTS = dict(pipeline=4, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1,
-                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=80000, visit_budget=384)
+                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=80000, visit_budget=384, group_split=1, split_min=8, split_paths=400000)
 
 
 def run(seed_arg, cases, ctx=None, log=print):
@@ -102,13 +102,14 @@ def run(seed_arg, cases, ctx=None, log=print):
         W = int(rng.choice([1, 7, 16, 37, 48, 64, 96, 100, 128, 160, 200, 256, 333, 384, 512, 640, 1024, 1920]))
         H = int(rng.choice([1, 5, 36, 54, 64, 90, 100, 108, 128, 211, 256, 360, 450, 600, 1080]))
         spp, depth = int(rng.integers(1, 5)), int(rng.integers(0, 9))
-        prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 6))
+        prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 9))
         world, rows = int(rng.choice([1, 1, 2, 3, 8])), int(rng.choice([10, 10, 7, 16, 1]))
         opts = dict(direct_slots=int(rng.random() < 0.8), sky_split=int(rng.random() < 0.8), wave_stage=int(rng.choice([0, 0, 0, 1, 2, 3, -1])),
                     trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3), lead_split=int(rng.random() < 0.8), resolve_inline=int(rng.random() < 0.8), batch_passes=int(rng.random() < 0.7), finish_in_trace=int(rng.random() < 0.4), auto_fused=int(rng.random() < 0.7))
         # the pass-batched pipeline's own switches: passes per group, staging, persistent waves, the wave-per-ray threshold, the visit budget
         gopts = dict(group_max=int(rng.choice([1, 2, 4, 64, 256])), trace_stage=int(rng.random() < 0.7), trace_persist=int(rng.random() < 0.7),
-                     wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 384])), sky_split=opts["sky_split"])
+                     wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 384])), sky_split=opts["sky_split"],
+                     group_split=int(rng.random() < 0.8), split_min=int(rng.choice([2, 2, 4, 8])), split_paths=int(rng.choice([0, 0, 400000])))
         res = []
         for pl in (0, 3, 4):
             ctx.set_option("pipeline", pl)
