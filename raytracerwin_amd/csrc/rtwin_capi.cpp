@@ -1233,6 +1233,7 @@ static int group_passes(const rtw_context* cx, long long paths_per_pass, int rem
         if (k == 1 || (bytes <= ((size_t)24 << 30) && paths_per_pass * k < ((long long)1 << 30))) break;
         k >>= 1;
     }
+    if (k < remaining && remaining < 2 * k) k = (remaining + 1) / 2;      // 20 passes at 16 per group: 10 + 10, not 16 + 4 (a small last group pays every launch's latency for little work)
     return (int)(k < remaining ? k : remaining);
 }
 
