@@ -53,6 +53,10 @@ def library():
         L = C.CDLL(_LIB)
         L.rtw_last_error.restype = C.c_char_p
         L.rtw_version.restype = C.c_char_p
+        if b"EMULATION" in L.rtw_version() and os.environ.get("RTW_TEST_EMULATION") != "1":
+            # tests/cpu_emul's host build of the same sources (AddressSanitizer runs): never a way to render without a GPU
+            raise ImportError("raytracerwin_amd: %s is the sanitizer harness's host build; it is loaded by tests/test_host_cpu.py only "
+                              "(RTW_TEST_EMULATION=1)" % _LIB)
         L.rtw_rand31.restype = C.c_uint32
         L.rtw_png_free.restype = None
         _lib = L

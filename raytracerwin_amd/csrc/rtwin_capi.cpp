@@ -223,7 +223,11 @@ int ensure_workspace(rtw_context* ctx, size_t bytes)
 extern "C" {
 
 const char* rtw_last_error(void) { return t_error.c_str(); }
+#ifdef HIPEMU_COMPUTE_UNITS      /* defined by tests/cpu_emul's stand-in for the HIP headers: this is the host build the sanitizers run, not the product */
+const char* rtw_version(void) { return "rtwin 0.1 (HOST EMULATION for sanitizer runs -- not the product)"; }
+#else
 const char* rtw_version(void) { return "rtwin 0.1 (gfx950)"; }
+#endif
 
 int rtw_context_create(int device_index, rtw_context** out)
 {
