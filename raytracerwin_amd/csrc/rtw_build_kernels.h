@@ -61,57 +61,70 @@ __device__ __forceinline__ float build_first_zero_rec(const float* __restrict__ 
     return pts[idx[recs[start + first / 3].tri * 3 + first % 3] * 3 + a];
 }
 
-// one level of the recursion: the nodes of cur[0 .. *n_cur) are split, their children appended to next[]
-__global__ __launch_bounds__(256) void build_level_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx,
-                                                          const BuildTri* __restrict__ src, BuildTri* __restrict__ dst, int32_t* __restrict__ leaf_order,
-                                                          const BuildNode* __restrict__ cur, const uint32_t* __restrict__ n_cur, BuildNode* __restrict__ next, uint32_t* __restrict__ n_next,
-                                                          RtwNode* __restrict__ nodes, int32_t* __restrict__ node_depth, uint32_t* __restrict__ level_count)
+// One node of a level: its box, its split, its children.  NW = 1: one wave does it all.  NW = 4: the four waves of the block share a BIG node --
+// each takes a quarter of the segment for the order-free parts (box: min / max; the count of triangles going left; the stable scatter, whose
+// quarters stay in order), wave 0 alone folds the centroids (that chain is sequential by definition) -- because the top of the tree is a handful
+// of nodes with thousands of triangles each, and one wave per node left the rest of the chip idle for most of the build's time.
+#define RTW_BUILD_BIG 2048
+template <int NW>
+__device__ __forceinline__ void build_split_node(const float* __restrict__ pts, const int32_t* __restrict__ idx, const BuildTri* __restrict__ src, BuildTri* __restrict__ dst,
+                                                 int32_t* __restrict__ leaf_order, const BuildNode nd, BuildNode* __restrict__ next, uint32_t* __restrict__ n_next,
+                                                 RtwNode* __restrict__ nodes, int32_t* __restrict__ node_depth, uint32_t* __restrict__ level_count,
+                                                 float* cb, float* part_f, int* part_i, int q)
 {
-    __shared__ float cbuf[4][192];
-    float* cb = cbuf[threadIdx.x >> 6];
-    const uint32_t nn = *n_cur;
     const int lane = lane_id();
-    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t w = wave0; w < nn; w += nwaves) {
-        const BuildNode nd = cur[w];
-        const int start = nd.start, n = nd.count;
-        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + start);      // record t: s4[3 t] = centroid | tri, s4[3 t + 1] = lo, s4[3 t + 2] = hi
-        // ---- bounds (RAabb::Expand over every vertex of the segment = over the triangles' own boxes; min / max are order-free) ----
-        float lox = FLT_MAX, loy = FLT_MAX, loz = FLT_MAX, hix = -FLT_MAX, hiy = -FLT_MAX, hiz = -FLT_MAX;
-        for (int t = lane; t < n; t += 256) {            // four independent loads in flight per lane
-            float4 lo[4], hi[4];
-            for (int u = 0; u < 4; u++) {
-                const int tt = t + 64 * u;
-                const bool in = tt < n;
-                lo[u] = in ? s4[3 * tt + 1] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
-                hi[u] = in ? s4[3 * tt + 2] : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
-            }
-            for (int u = 0; u < 4; u++) {
-                if (lo[u].x < lox) lox = lo[u].x; if (lo[u].y < loy) loy = lo[u].y; if (lo[u].z < loz) loz = lo[u].z;
-                if (hi[u].x > hix) hix = hi[u].x; if (hi[u].y > hiy) hiy = hi[u].y; if (hi[u].z > hiz) hiz = hi[u].z;
-            }
+    const int start = nd.start, n = nd.count;
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + start);      // record t: s4[3 t] = centroid | tri, s4[3 t + 1] = lo, s4[3 t + 2] = hi
+    // this wave's part of the segment (whole 64s)
+    const int per = NW == 1 ? n : ((n + 64 * NW - 1) / (64 * NW)) * 64;
+    const int ps = NW == 1 ? 0 : (per * q < n ? per * q : n), pe = NW == 1 ? n : (ps + per < n ? ps + per : n);
+    // ---- bounds (RAabb::Expand over every vertex of the segment = over the triangles' own boxes; min / max are order-free) ----
+    float lox = FLT_MAX, loy = FLT_MAX, loz = FLT_MAX, hix = -FLT_MAX, hiy = -FLT_MAX, hiz = -FLT_MAX;
+    for (int t = ps + lane; t < pe; t += 256) {            // four independent loads in flight per lane
+        float4 lo[4], hi[4];
+        for (int u = 0; u < 4; u++) {
+            const int tt = t + 64 * u;
+            const bool in = tt < pe;
+            lo[u] = in ? s4[3 * tt + 1] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+            hi[u] = in ? s4[3 * tt + 2] : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
         }
-        lox = wave_min(lox); loy = wave_min(loy); loz = wave_min(loz); hix = wave_max(hix); hiy = wave_max(hiy); hiz = wave_max(hiz);
-        // +0 and -0 compare equal: the reference's sequential Expand keeps whichever zero it met FIRST; the parallel reduction may hold the other
-        if (lox == 0.0f) lox = build_first_zero_rec(pts, idx, src, start, n, 0);
-        if (loy == 0.0f) loy = build_first_zero_rec(pts, idx, src, start, n, 1);
-        if (loz == 0.0f) loz = build_first_zero_rec(pts, idx, src, start, n, 2);
-        if (hix == 0.0f) hix = build_first_zero_rec(pts, idx, src, start, n, 0);
-        if (hiy == 0.0f) hiy = build_first_zero_rec(pts, idx, src, start, n, 1);
-        if (hiz == 0.0f) hiz = build_first_zero_rec(pts, idx, src, start, n, 2);
-        RtwNode rec;
-        rec.min_x = lox; rec.min_y = loy; rec.min_z = loz; rec.max_x = hix; rec.max_y = hiy; rec.max_z = hiz;
-        rec.skip = nd.index + 2 * n - 1;
-        if (n == 1) {                    // a leaf: its slot in leaf order is its place in the triangle order
-            const int tri = __float_as_int(s4[0].w);
-            rec.tri = start;
-            if (lane == 0) { nodes[nd.index] = rec; node_depth[nd.index] = nd.depth; leaf_order[start] = tri; }
-            continue;
+        for (int u = 0; u < 4; u++) {
+            if (lo[u].x < lox) lox = lo[u].x; if (lo[u].y < loy) loy = lo[u].y; if (lo[u].z < loz) loz = lo[u].z;
+            if (hi[u].x > hix) hix = hi[u].x; if (hi[u].y > hiy) hiy = hi[u].y; if (hi[u].z > hiz) hiz = hi[u].z;
         }
-        rec.tri = -1;
-        // ---- NodeMidPoint: the centroids summed in list order (one chain of dependent adds), then / NumTriangles; the next 64 centroids
-        // are fetched while the chain folds the current ones ----
-        // (lanes 0, 1, 2 fold x, y, z: one LDS read and one add per element for the three axes together, instead of three v_readlane + add pairs)
+    }
+    lox = wave_min(lox); loy = wave_min(loy); loz = wave_min(loz); hix = wave_max(hix); hiy = wave_max(hiy); hiz = wave_max(hiz);
+    if (NW > 1) {
+        if (lane == 0) { float* o = part_f + 6 * q; o[0] = lox; o[1] = loy; o[2] = loz; o[3] = hix; o[4] = hiy; o[5] = hiz; }
+        __syncthreads();
+        for (int k = 0; k < NW; k++) {
+            const float* o = part_f + 6 * k;
+            if (o[0] < lox) lox = o[0]; if (o[1] < loy) loy = o[1]; if (o[2] < loz) loz = o[2];
+            if (o[3] > hix) hix = o[3]; if (o[4] > hiy) hiy = o[4]; if (o[5] > hiz) hiz = o[5];
+        }
+        __syncthreads();
+    }
+    // +0 and -0 compare equal: the reference's sequential Expand keeps whichever zero it met FIRST; the parallel reduction may hold the other
+    if (lox == 0.0f) lox = build_first_zero_rec(pts, idx, src, start, n, 0);
+    if (loy == 0.0f) loy = build_first_zero_rec(pts, idx, src, start, n, 1);
+    if (loz == 0.0f) loz = build_first_zero_rec(pts, idx, src, start, n, 2);
+    if (hix == 0.0f) hix = build_first_zero_rec(pts, idx, src, start, n, 0);
+    if (hiy == 0.0f) hiy = build_first_zero_rec(pts, idx, src, start, n, 1);
+    if (hiz == 0.0f) hiz = build_first_zero_rec(pts, idx, src, start, n, 2);
+    RtwNode rec;
+    rec.min_x = lox; rec.min_y = loy; rec.min_z = loz; rec.max_x = hix; rec.max_y = hiy; rec.max_z = hiz;
+    rec.skip = nd.index + 2 * n - 1;
+    if (n == 1) {                    // a leaf: its slot in leaf order is its place in the triangle order  (never a shared node)
+        const int tri = __float_as_int(s4[0].w);
+        rec.tri = start;
+        if (lane == 0) { nodes[nd.index] = rec; node_depth[nd.index] = nd.depth; leaf_order[start] = tri; }
+        return;
+    }
+    rec.tri = -1;
+    // ---- NodeMidPoint: the centroids summed in list order (one chain of dependent adds per axis), then / NumTriangles; the next 64 centroids
+    // are fetched while the chain folds the current ones (lanes 0, 1, 2 fold x, y, z out of LDS) ----
+    float mx = 0.0f, my = 0.0f, mz = 0.0f;
+    if (NW == 1 || q == 0) {
         float m = 0.0f;
         float4 cn = lane < n ? s4[3 * lane] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int t0 = 0; t0 < n; t0 += 64) {
@@ -121,62 +134,115 @@ __global__ __launch_bounds__(256) void build_level_kernel(const float* __restric
             cn = tn < n ? s4[3 * tn] : make_float4(0.f, 0.f, 0.f, 0.f);
             cb[lane * 3] = c.x; cb[lane * 3 + 1] = c.y; cb[lane * 3 + 2] = c.z;
             wave_lds_sync();
-            if (lane < 3) for (int j = 0; j < cnt; j++) m = m + cb[j * 3 + lane];
+            if (lane < 3) {
+                for (int j0 = 0; j0 < cnt; j0 += 16) {      // sixteen LDS reads in flight, then their sixteen dependent adds (a read per add waited ~70 cycles each)
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) v[u] = cb[(j0 + u) * 3 + lane];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (j0 + u < cnt) m = m + v[u];
+                }
+            }
             wave_lds_sync();
         }
         const float fn = (float)n;
-        const float mx = readlane_f(m, 0) / fn, my = readlane_f(m, 1) / fn, mz = readlane_f(m, 2) / fn;
-        // ---- GetLargestAxisOfBounds ----
-        const float sx = hix - lox, sy = hiy - loy, sz = hiz - loz;
-        const int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);
-        const float cut = axis == 0 ? mx : (axis == 1 ? my : mz);
-        // ---- how many go left ----
-        int n_left = 0;
-        for (int t0 = 0; t0 < n; t0 += 256) {
-            float4 c[4];
-            for (int u = 0; u < 4; u++) { const int tt = t0 + 64 * u + lane; c[u] = tt < n ? s4[3 * tt] : make_float4(0.f, 0.f, 0.f, 0.f); }
-            for (int u = 0; u < 4; u++) {
-                const int tt = t0 + 64 * u + lane;
-                const float v = axis == 0 ? c[u].x : (axis == 1 ? c[u].y : c[u].z);
-                n_left += (int)__popcll(__ballot(tt < n && v < cut));
-            }
+        mx = readlane_f(m, 0) / fn; my = readlane_f(m, 1) / fn; mz = readlane_f(m, 2) / fn;
+        if (NW > 1 && lane == 0) { part_f[0] = mx; part_f[1] = my; part_f[2] = mz; }
+    }
+    if (NW > 1) { __syncthreads(); mx = part_f[0]; my = part_f[1]; mz = part_f[2]; __syncthreads(); }
+    // ---- GetLargestAxisOfBounds ----
+    const float sx = hix - lox, sy = hiy - loy, sz = hiz - loz;
+    const int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);
+    const float cut = axis == 0 ? mx : (axis == 1 ? my : mz);
+    // ---- how many go left (in this wave's part) ----
+    int my_left = 0;
+    for (int t0 = ps; t0 < pe; t0 += 256) {
+        float4 c[4];
+        for (int u = 0; u < 4; u++) { const int tt = t0 + 64 * u + lane; c[u] = tt < pe ? s4[3 * tt] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int u = 0; u < 4; u++) {
+            const int tt = t0 + 64 * u + lane;
+            const float v = axis == 0 ? c[u].x : (axis == 1 ? c[u].y : c[u].z);
+            my_left += (int)__popcll(__ballot(tt < pe && v < cut));
         }
-        const bool one_sided = n_left == 0 || n_left == n;
-        if (one_sided) n_left = n / 2;
-        // ---- the two sides, each in list order: the records move with their triangles ----
-        float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + start);
-        int done_l = 0, done_r = 0;
-        for (int t0 = 0; t0 < n; t0 += 128) {
-            float4 r0[2], r1[2], r2[2];
-            for (int u = 0; u < 2; u++) {
-                const int tt = t0 + 64 * u + lane;
-                if (tt < n) { r0[u] = s4[3 * tt]; r1[u] = s4[3 * tt + 1]; r2[u] = s4[3 * tt + 2]; }
-                else { r0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r1[u] = r0[u]; r2[u] = r0[u]; }
-            }
-            for (int u = 0; u < 2; u++) {
-                const int tt = t0 + 64 * u + lane;
-                const bool mine = tt < n;
-                bool left = false;
-                if (mine) {
-                    if (one_sided) left = tt < n_left;
-                    else { const float v = axis == 0 ? r0[u].x : (axis == 1 ? r0[u].y : r0[u].z); left = v < cut; }
-                }
-                const unsigned long long ml = __ballot(mine && left), mr = __ballot(mine && !left);
-                if (mine) {
-                    const int at = left ? done_l + mbcnt(ml) : n_left + done_r + mbcnt(mr);
-                    d4[3 * at] = r0[u]; d4[3 * at + 1] = r1[u]; d4[3 * at + 2] = r2[u];
-                }
-                done_l += (int)__popcll(ml); done_r += (int)__popcll(mr);
-            }
+    }
+    int n_left = my_left, left_before = 0;          // left_before: lefts in the parts before this wave's
+    if (NW > 1) {
+        if (lane == 0) part_i[q] = my_left;
+        __syncthreads();
+        n_left = 0;
+        for (int k = 0; k < NW; k++) { if (k < q) left_before += part_i[k]; n_left += part_i[k]; }
+        __syncthreads();
+    }
+    const bool one_sided = n_left == 0 || n_left == n;
+    if (one_sided) { n_left = n / 2; left_before = ps < n_left ? ps : n_left; }
+    const int right_before = ps - left_before;
+    // ---- the two sides, each in list order: the records move with their triangles ----
+    float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + start);
+    int done_l = 0, done_r = 0;
+    for (int t0 = ps; t0 < pe; t0 += 128) {
+        float4 r0[2], r1[2], r2[2];
+        for (int u = 0; u < 2; u++) {
+            const int tt = t0 + 64 * u + lane;
+            if (tt < pe) { r0[u] = s4[3 * tt]; r1[u] = s4[3 * tt + 1]; r2[u] = s4[3 * tt + 2]; }
+            else { r0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r1[u] = r0[u]; r2[u] = r0[u]; }
         }
-        if (lane == 0) {
-            nodes[nd.index] = rec; node_depth[nd.index] = nd.depth;
-            const uint32_t at = atomicAdd(n_next, 2u);
-            BuildNode l, r;
-            l.start = start; l.count = n_left; l.index = nd.index + 1; l.depth = nd.depth + 1;
-            r.start = start + n_left; r.count = n - n_left; r.index = nd.index + 2 * n_left; r.depth = nd.depth + 1;
-            next[at] = l; next[at + 1] = r;
-            atomicAdd(&level_count[nd.depth + 1 < 63 ? nd.depth + 1 : 63], 2u);
+        for (int u = 0; u < 2; u++) {
+            const int tt = t0 + 64 * u + lane;
+            const bool mine = tt < pe;
+            bool left = false;
+            if (mine) {
+                if (one_sided) left = tt < n_left;
+                else { const float v = axis == 0 ? r0[u].x : (axis == 1 ? r0[u].y : r0[u].z); left = v < cut; }
+            }
+            const unsigned long long ml = __ballot(mine && left), mr = __ballot(mine && !left);
+            if (mine) {
+                const int at = left ? left_before + done_l + mbcnt(ml) : n_left + right_before + done_r + mbcnt(mr);
+                d4[3 * at] = r0[u]; d4[3 * at + 1] = r1[u]; d4[3 * at + 2] = r2[u];
+            }
+            done_l += (int)__popcll(ml); done_r += (int)__popcll(mr);
+        }
+    }
+    if (lane == 0 && (NW == 1 || q == 0)) {
+        nodes[nd.index] = rec; node_depth[nd.index] = nd.depth;
+        const uint32_t at = atomicAdd(n_next, 2u);
+        BuildNode l, r;
+        l.start = start; l.count = n_left; l.index = nd.index + 1; l.depth = nd.depth + 1;
+        r.start = start + n_left; r.count = n - n_left; r.index = nd.index + 2 * n_left; r.depth = nd.depth + 1;
+        next[at] = l; next[at + 1] = r;
+        atomicAdd(&level_count[nd.depth + 1 < 63 ? nd.depth + 1 : 63], 2u);
+    }
+}
+
+// one level of the recursion: the nodes of cur[0 .. *n_cur) are split, their children appended to next[].  A block takes four nodes: its waves one
+// each, except that a node of RTW_BUILD_BIG triangles or more is shared by the whole block (block-uniform branch: every thread reads the same record)
+__global__ __launch_bounds__(256) void build_level_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx,
+                                                          const BuildTri* __restrict__ src, BuildTri* __restrict__ dst, int32_t* __restrict__ leaf_order,
+                                                          const BuildNode* __restrict__ cur, const uint32_t* __restrict__ n_cur, BuildNode* __restrict__ next, uint32_t* __restrict__ n_next,
+                                                          RtwNode* __restrict__ nodes, int32_t* __restrict__ node_depth, uint32_t* __restrict__ level_count, int block_per_node)
+{
+    __shared__ float cbuf[4][192];
+    __shared__ float part_f[24];
+    __shared__ int part_i[4];
+    const int q = (int)(threadIdx.x >> 6);
+    float* cb = cbuf[q];
+    const uint32_t nn = *n_cur;
+    if (block_per_node) {       // the first levels: few nodes, big ones -- a block each, so that the big nodes of a level run side by side
+        for (uint32_t w = blockIdx.x; w < nn; w += gridDim.x) {
+            const BuildNode nd = cur[w];
+            if (nd.count >= RTW_BUILD_BIG) build_split_node<4>(pts, idx, src, dst, leaf_order, nd, next, n_next, nodes, node_depth, level_count, cb, part_f, part_i, q);
+            else if (q == 0) build_split_node<1>(pts, idx, src, dst, leaf_order, nd, next, n_next, nodes, node_depth, level_count, cb, part_f, part_i, 0);
+        }
+        return;
+    }
+    for (uint32_t g0 = blockIdx.x * 4u; g0 < nn; g0 += gridDim.x * 4u) {
+        for (uint32_t i = 0; i < 4u && g0 + i < nn; i++) {
+            const BuildNode nd = cur[g0 + i];
+            if (nd.count >= RTW_BUILD_BIG) build_split_node<4>(pts, idx, src, dst, leaf_order, nd, next, n_next, nodes, node_depth, level_count, cb, part_f, part_i, q);
+        }
+        const uint32_t w = g0 + (uint32_t)q;
+        if (w < nn) {
+            const BuildNode nd = cur[w];
+            if (nd.count < RTW_BUILD_BIG) build_split_node<1>(pts, idx, src, dst, leaf_order, nd, next, n_next, nodes, node_depth, level_count, cb, part_f, part_i, 0);
         }
     }
 }

@@ -2458,11 +2458,12 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
             const int c = level & 1;
             RTW_HIP_OK(hipMemsetAsync(&d_cnt[1 - c], 0, 4, stream));
             // a wave per node; at most n nodes on a level, the stride loop takes any excess
-            unsigned blocks = (unsigned)(((long long)(n < (1 << level) || level > 20 ? n : (1 << level)) + 3) / 4);
+            const int block_per_node = level <= 7 ? 1 : 0;      // at most 128 nodes: a block each (its four waves share a big node)
+            unsigned blocks = block_per_node ? (unsigned)(1 << level) : (unsigned)(((long long)(n < (1 << level) || level > 20 ? n : (1 << level)) + 3) / 4);
             if (blocks > 8192u) blocks = 8192u;
             if (blocks < 1u) blocks = 1u;
             hipLaunchKernelGGL(build_level_kernel, dim3(blocks), dim3(256), 0, stream, d_pts, d_ip, d_rec[c], d_rec[1 - c], d_leaf, d_lvl[c], &d_cnt[c], d_lvl[1 - c], &d_cnt[1 - c],
-                               o.nodes, d_depth, &d_cnt[2]);
+                               o.nodes, d_depth, &d_cnt[2], block_per_node);
         }
         uint32_t left = 0;
         RTW_HIP_OK(hipMemcpyAsync(&left, &d_cnt[level & 1], 4, hipMemcpyDeviceToHost, stream));
