@@ -508,7 +508,7 @@ def main():
             "bins_and_tables_build_ms": max(0.0, first_call_ms - second_call_ms),
             "tree_and_bins_build_ms": build_ms,
             "host_setup_note": "scene_commit_ms = tree build (on the device by default, the reference's split decisions) + derived layouts + upload / read-back; bins_and_tables_build_ms = "
-                               "first render call of this frame shape minus the second (screen bins on the device, busy / sky tile lists and job table on the host); "
+                               "first render call of this frame shape minus the second (screen bins on the device, busy / sky tile lists and job table on the host, the two group workspaces' hipMalloc); "
                                "tree_and_bins_build_ms times both constructions, device and host, on fresh scenes (two runs each, alternating, the faster kept; commit_ms includes the texture atlas upload, the same either way); none of it is in the timed region",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
