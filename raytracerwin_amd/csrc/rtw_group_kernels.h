@@ -28,7 +28,9 @@
 #define RTW_GT_COUNT(x) (void)0
 #endif
 #define RTW_GT_CAP 16           // candidate leaves a lane of gtrace_kernel notes before the wave runs its triangle tests (256-thread blocks, nothing staged)
+#ifndef RTW_GT_CAP_STAGED
 #define RTW_GT_CAP_STAGED 8     // ... in the 1024-thread blocks that stage a tree's upper levels in LDS
+#endif
 
 struct GroupBufs {
     float4* __restrict__ rad;       // [capacity]      radiance of a finished path
