@@ -28,6 +28,9 @@
 #define RTW_GT_COUNT(x) (void)0
 #endif
 #define RTW_GT_CAP 16           // candidate leaves a lane of gtrace_kernel notes before the wave runs its triangle tests (256-thread blocks, nothing staged)
+#ifndef RTW_GT_UNROLL
+#define RTW_GT_UNROLL 4      // measured 1 / 2 / 3 / 4 / 8 visits per look: C2 0.895 / 0.879 / 0.890 / 0.860 / 0.870 ms per 20 passes, C4 4.94 / 4.83 / 4.71 / 4.73 / 4.74
+#endif
 #ifndef RTW_GT_CAP_STAGED
 #define RTW_GT_CAP_STAGED 8     // ... in the 1024-thread blocks that stage a tree's upper levels in LDS
 #endif
@@ -473,9 +476,11 @@ __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* 
         // ---- walk: every lane steps through its own records until all are done or some lane's list is full ----
         if (!any_untame) {
             for (;;) {
-                const bool walking = i < n_nodes;
-                if (__ballot(walking) == 0ull) break;
+                if (__ballot(i < n_nodes) == 0ull) break;
                 RTW_GT_COUNT(dbg_walk);
+#pragma unroll
+                for (int u = 0; u < RTW_GT_UNROLL; u++) {        // several visits between two looks at the wave (see gtrace_persist_kernel)
+                const bool walking = (i < n_nodes) & (ncand < CAP);
                 if (walking) {
                     float4 a, b;
                     if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
@@ -490,6 +495,7 @@ __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* 
                     if (STATS) ct.boxes++;
                     if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
                     i = (hit & !leaf) ? ~link : skip;
+                }
                 }
                 if (__ballot(ncand == CAP) != 0ull) break;
             }
@@ -805,9 +811,13 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
             const rtw_v2f ox = { r.o.x, r.o.x }, oy = { r.o.y, r.o.y }, oz = { r.o.z, r.o.z };
             const rtw_v2f vx = { ix, ix }, vy = { iy, iy }, vz = { iz, iz };
             for (;;) {
-                const bool walking = have & (i < n_nodes);
-                if (__ballot(walking) == 0ull) break;
+                if (__ballot(have & (i < n_nodes)) == 0ull) break;
                 RTW_GT_COUNT(dbg_walk);
+                // RTW_GT_UNROLL visits between two looks at the wave (the three ballots, their scalar compares and branches: a CU has ONE scalar
+                // unit for its sixteen waves); a lane whose list is full sits the extra visits out, its sequence of visits is the same
+#pragma unroll
+                for (int u = 0; u < RTW_GT_UNROLL; u++) {
+                const bool walking = have & (i < n_nodes) & (ncand < CAP);
                 if (walking) {
                     float4 a, b;
                     if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
@@ -823,6 +833,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
                     i = (hit & !leaf) ? ~link : skip;
                     visits++;
+                }
                 }
                 if (__ballot(ncand == CAP) != 0ull) break;
                 if (!exhausted && __popcll(__ballot(have & (i >= n_nodes))) >= RTW_GT_REFILL) break;
