@@ -691,7 +691,9 @@ __device__ __forceinline__ uint32_t batch_entry(uint32_t batch, uint32_t n_batch
     count = n - first < 64u ? n - first : 64u;
     return first + lane < n ? first + lane : 0xFFFFFFFFu;
 }
+#ifndef RTW_GT_REFILL
 #define RTW_GT_REFILL 16
+#endif
 template <bool STATS, int NT, int CAP, int STAGE>
 __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
 {
