@@ -230,8 +230,8 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                       int sub_samples, uint32_t seed);
 
 /* ---- multi-GPU: the one exchange of the path.  Every rank renders its own tasks (rtw_render_tasks / rtw_render_passes with rank, world)
- * into a full-size framebuffer; rtw_gather_rows then moves every rank's rows to rank 0 over RCCL (xGMI): grouped ncclSend / ncclRecv
- * straight out of / into the framebuffers' device memory, on the context's stream, no staging copies.  No reference counterpart (the
+ * into a full-size framebuffer; rtw_gather_rows then moves every rank's rows to rank 0 over RCCL (xGMI): one ncclSend / ncclRecv
+ * per peer of a compact block of the rank's rows, on the context's stream.  No reference counterpart (the
  * reference is one process); it completes what UpdateBitmapPixels' WaitForAllTasksDone (Src/RayTracerProgram.cpp:303) is to one process.
  * librccl is loaded on first use (dlopen: the library the environment variable RTW_RCCL_LIBRARY names if it is set, else the copy already in the
  * process, e.g. PyTorch's, else librccl.so.1); single-GPU users never load it. ---- */
@@ -246,9 +246,13 @@ int rtw_comm_wrap(rtw_context* ctx, void* nccl_comm, int rank, int world, rtw_co
 int rtw_comm_destroy(rtw_comm* comm);
 #define RTW_GATHER_ALL 0        /* accumulator (16 B / pixel) + ARGB (4 B / pixel) */
 #define RTW_GATHER_ARGB 1       /* the displayable image only, 4 B / pixel */
-/* rows of task t (task_rows rows each, as rtw_render_tasks deals them: t belongs to rank t % world) travel from their owner to rank 0.
- * Asynchronous on the context's stream; every rank of the communicator must call it. */
+/* rows of task t (task_rows rows each, as rtw_render_tasks deals them: t belongs to rank t % world) travel from their owner to rank 0:
+ * ONE message per peer -- a sender packs its rows into a compact block (a kernel), the root receives every peer's block inside one RCCL group and
+ * unpacks them with one launch; the staging blocks (a rank's share of the frame x 4 or 20 bytes per pixel; the root holds every peer's) are
+ * allocated by the first gather of a frame shape.  Asynchronous on the context's stream; every rank of the communicator must call it. */
 int rtw_gather_rows(rtw_comm* comm, rtw_framebuffer* fb, int task_rows, int mode);
+/* ncclSend / ncclRecv operations this communicator has issued so far (a gather costs a sender one, the root world - 1) */
+long long rtw_comm_messages(const rtw_comm* comm);
 
 /* work counters of launches since the last reset (only counted while enabled) */
 int rtw_stats_enable(rtw_context* ctx, int enabled);

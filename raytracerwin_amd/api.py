@@ -338,6 +338,12 @@ class Comm:
     def gather_rows(self, fb, task_rows, argb_only=False):
         _check(library().rtw_gather_rows(self.h, fb.h, int(task_rows), 1 if argb_only else 0))
 
+    def messages(self):
+        """ncclSend / ncclRecv operations issued so far: a gather costs a sender one, the root world - 1"""
+        L = library()
+        L.rtw_comm_messages.restype = C.c_longlong
+        return int(L.rtw_comm_messages(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             library().rtw_comm_destroy(self.h)

@@ -105,5 +105,10 @@ int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float*
 int launch_ray_trace(const RtwSceneDev* sc, const float* rays, const uint32_t* keys2, long long n, int max_bounce, int preview,
                      uint32_t seed, unsigned long long npix, float* rgb, void* ws, bool stats, hipStream_t stream);
 int launch_texture_sample(const RtwSceneDev* sc, int shape, int mat, const float* uv, long long n, float* rgba, hipStream_t stream);
+// ---- multi-GPU gather (rtw_gather_rows): every rank's task rows travel as ONE compact block per rank -- [ARGB of its pixels in task order |
+// their accumulators] -- packed by the sender, unpacked into the framebuffer by the root, all peers in one launch ----
+struct GatherBlocks { int n = 0, first_rank = 0; uint64_t off[64]; uint32_t px[64]; };     // blocks of ranks first_rank .. first_rank + n - 1 inside the staging buffer
+size_t gather_block_bytes(size_t pixels, bool with_accum);
+int launch_gather_rows(bool unpack, void* argb, void* accum, void* stage, int width, int task_rows, int world, const GatherBlocks& b, bool with_accum, hipStream_t stream);
 
 }  // namespace rtw

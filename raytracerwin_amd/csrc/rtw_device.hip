@@ -1888,6 +1888,47 @@ __global__ void texture_sample_kernel(const RtwSceneDev* __restrict__ sc, int sh
     rgba[i * 4] = c.x; rgba[i * 4 + 1] = c.y; rgba[i * 4 + 2] = c.z; rgba[i * 4 + 3] = a;
 }
 
+// ---- multi-GPU gather: a rank's task rows <-> one compact block ---------------------------------------------------------------
+// The tasks of rank r (task_rows rows each, t = r, r + world, ...: Src/RayTracerProgram.cpp:282,294-301 dealt round-robin) lie scattered
+// over the frame; RCCL moves ONE message per peer, so a sender first PACKS its rows into a compact block -- [ARGB of its pixels in task
+// order | their accumulators] -- and the root UNPACKS every peer's block into its framebuffer (blockIdx.y = peer).  Pixel l of rank r's
+// block is pixel (r + (l / task_px) * world) * task_px + l % task_px of the frame (only the frame's last task can be short, and it is
+// the last of its owner's).  VEC: four pixels per thread (the frame's width divides by 4, so every offset does).
+struct GatherPlan {
+    uint32_t* argb; float4* accum;      // the framebuffer
+    char* stage;                        // compact blocks: rank r's starts at stage + block_off[r - first_rank]
+    int32_t task_px;                    // task_rows * width
+    int32_t world, first_rank, with_accum;
+    uint64_t block_off[64];             // byte offset of peer k's block (k = blockIdx.y), a multiple of 256
+    uint32_t block_px[64];              // its pixels
+};
+template <bool UNPACK, bool VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherPlan g)
+{
+    const uint32_t k = blockIdx.y;
+    const uint32_t n = g.block_px[k];
+    const uint32_t r = (uint32_t)g.first_rank + k;
+    char* blk = g.stage + g.block_off[k];
+    uint32_t* b_argb = reinterpret_cast<uint32_t*>(blk);
+    float4* b_accum = reinterpret_cast<float4*>(blk + (((size_t)n * 4 + 255) & ~(size_t)255));
+    const uint32_t step = VEC ? 4u : 1u;
+    for (uint32_t l = (blockIdx.x * blockDim.x + threadIdx.x) * step; l < n; l += gridDim.x * blockDim.x * step) {
+        const uint32_t j = l / (uint32_t)g.task_px, within = l - j * (uint32_t)g.task_px;
+        const size_t pixel = (size_t)(r + j * (uint32_t)g.world) * (size_t)g.task_px + within;
+        if (VEC) {
+            float4* fa = reinterpret_cast<float4*>(g.argb + pixel); float4* ba = reinterpret_cast<float4*>(b_argb + l);      // (a 16-byte move; no arithmetic)
+            if (UNPACK) *fa = *ba; else *ba = *fa;
+        } else {
+            if (UNPACK) g.argb[pixel] = b_argb[l]; else b_argb[l] = g.argb[pixel];
+        }
+        if (g.with_accum) {
+            for (uint32_t e = 0; e < step; e++) {
+                if (UNPACK) g.accum[pixel + e] = b_accum[l + e]; else b_accum[l + e] = g.accum[pixel + e];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------
@@ -2563,6 +2604,32 @@ int launch_texture_sample(const RtwSceneDev* sc, int shape, int mat, const float
     const int block = 256;
     const unsigned grid = (unsigned)((n + block - 1) / block);
     hipLaunchKernelGGL(texture_sample_kernel, dim3(grid), dim3(block), 0, stream, sc, shape, mat, uv, n, rgba);
+    return (int)hipGetLastError();
+}
+
+// ---- multi-GPU gather: pack / unpack of the ranks' compact row blocks (gather_rows_kernel) --------------------------------------
+size_t gather_block_bytes(size_t pixels, bool with_accum)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(pixels * 4) + (with_accum ? up(pixels * 16) : 0);
+}
+
+int launch_gather_rows(bool unpack, void* argb, void* accum, void* stage, int width, int task_rows, int world, const GatherBlocks& b, bool with_accum, hipStream_t stream)
+{
+    if (b.n <= 0) return 0;
+    GatherPlan g;
+    g.argb = (uint32_t*)argb; g.accum = (float4*)accum; g.stage = (char*)stage;
+    g.task_px = task_rows * width; g.world = world; g.first_rank = b.first_rank; g.with_accum = with_accum ? 1 : 0;
+    uint32_t most = 0;
+    for (int k = 0; k < 64; k++) { g.block_off[k] = k < b.n ? b.off[k] : 0; g.block_px[k] = k < b.n ? b.px[k] : 0; if (g.block_px[k] > most) most = g.block_px[k]; }
+    if (most == 0) return 0;
+    const bool vec = width % 4 == 0;
+    unsigned gx = (unsigned)((most / (vec ? 4u : 1u) + 255u) / 256u);
+    if (gx < 1u) gx = 1u;
+    if (gx > 4096u) gx = 4096u;
+    const dim3 grid(gx, (unsigned)b.n);
+    if (unpack) { if (vec) hipLaunchKernelGGL((gather_rows_kernel<true, true>), grid, dim3(256), 0, stream, g); else hipLaunchKernelGGL((gather_rows_kernel<true, false>), grid, dim3(256), 0, stream, g); }
+    else { if (vec) hipLaunchKernelGGL((gather_rows_kernel<false, true>), grid, dim3(256), 0, stream, g); else hipLaunchKernelGGL((gather_rows_kernel<false, false>), grid, dim3(256), 0, stream, g); }
     return (int)hipGetLastError();
 }
 

@@ -1686,12 +1686,12 @@ const RcclApi* rccl_api()
     void* h = nullptr;
     if (const char* named = std::getenv("RTW_RCCL_LIBRARY")) {      // a deployment's own RCCL build (include/rtwin.h)
         h = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
-        if (!h) { g_rccl.error = std::string("RTW_RCCL_LIBRARY: ") + (dlerror() ? dlerror() : "cannot load"); return nullptr; }
+        if (!h) { const char* e = dlerror(); g_rccl.error = std::string("RTW_RCCL_LIBRARY: ") + (e ? e : "cannot load"); return nullptr; }       // (dlerror() clears the message: one call)
     }
     for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { g_rccl.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+    if (!h) { const char* e = dlerror(); g_rccl.error = std::string("cannot load librccl: ") + (e ? e : "?"); return nullptr; }
     RcclApi a; a.handle = h;
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
@@ -1718,6 +1718,9 @@ struct rtw_comm {
     ncclComm_t comm = nullptr;
     bool owned = false;
     int rank = 0, world = 1;
+    void* d_stage = nullptr;            // compact row blocks of rtw_gather_rows (this rank's on a sender, every peer's on the root); grow-only
+    size_t stage_bytes = 0;
+    long long messages = 0;             // ncclSend / ncclRecv operations issued so far (rtw_comm_messages)
 };
 
 extern "C" {
@@ -1769,6 +1772,7 @@ int rtw_comm_destroy(rtw_comm* comm)
         const RcclApi* a = rccl_api();
         if (a) (void)a->CommDestroy(comm->comm);
     }
+    if (comm->d_stage) { (void)hipSetDevice(comm->ctx->device); (void)hipStreamSynchronize(comm->ctx->stream); (void)hipFree(comm->d_stage); }
     delete comm;
     return RTW_OK;
 }
@@ -1779,36 +1783,67 @@ int rtw_gather_rows(rtw_comm* comm, rtw_framebuffer* fb, int task_rows, int mode
     if (fb->ctx != comm->ctx) return fail(RTW_ERR_INVALID, "communicator and framebuffer belong to different contexts");
     if (task_rows < 1 || (mode != RTW_GATHER_ALL && mode != RTW_GATHER_ARGB)) return fail(RTW_ERR_INVALID, "bad argument");
     if (comm->world == 1) return RTW_OK;
+    if (comm->world > 65) return fail(RTW_ERR_LIMIT, "rtw_gather_rows: at most 65 ranks");
     const RcclApi* a = rccl_api();
     if (!a) return fail(RTW_ERR_STATE, g_rccl.error);
     HIP_TRY(hipSetDevice(comm->ctx->device));
     hipStream_t st = comm->ctx->stream;
-    const int W = fb->width, H = fb->height;
+    const int W = fb->width, H = fb->height, world = comm->world;
+    if ((int64_t)task_rows * W > INT32_MAX) return fail(RTW_ERR_LIMIT, "task too large");
     const int n_tasks = (H + task_rows - 1) / task_rows;
+    const bool with_accum = mode == RTW_GATHER_ALL;
+    // ONE message per peer: a sender packs its task rows (scattered over the frame) into a compact block, the root receives every peer's block
+    // into its staging buffer inside one RCCL group and unpacks them all with one launch.  (Round 2 sent every 10-row task on its own: ~100 small
+    // messages per gather at 1080p, whose per-message cost was of the order of the whole timed region.)
+    auto pixels_of = [&](int r) -> size_t {
+        if (n_tasks <= r) return 0;
+        const int mine = (n_tasks - r + world - 1) / world;
+        size_t px = (size_t)mine * (size_t)task_rows * (size_t)W;
+        if ((n_tasks - 1) % world == r) px -= (size_t)(n_tasks * task_rows - H) * (size_t)W;      // the frame's last task may be short
+        return px;
+    };
+    rtw::GatherBlocks b;
+    size_t total = 0;
+    if (comm->rank == 0) {
+        b.first_rank = 1; b.n = world - 1;
+        for (int r = 1; r < world; r++) { b.off[r - 1] = total; b.px[r - 1] = (uint32_t)pixels_of(r); total += rtw::gather_block_bytes(pixels_of(r), with_accum); }
+    } else {
+        b.first_rank = comm->rank; b.n = 1; b.off[0] = 0; b.px[0] = (uint32_t)pixels_of(comm->rank);
+        total = rtw::gather_block_bytes(pixels_of(comm->rank), with_accum);
+    }
+    if (total > comm->stage_bytes) {        // grow-only; the first gather of a frame shape pays it (bench.py's warm-up gather does)
+        HIP_TRY(hipStreamSynchronize(st));
+        if (comm->d_stage) { (void)hipFree(comm->d_stage); comm->d_stage = nullptr; comm->stage_bytes = 0; }
+        HIP_TRY(hipMalloc(&comm->d_stage, total));
+        comm->stage_bytes = total;
+    }
     ncclResult_t r = ncclSuccess;
-    // a task's rows are contiguous in both buffers; ranks and root walk the tasks in the same order, so the point-to-point operations of a
-    // pair match up in issue order.  Groups of 64 tasks keep the number of operations per group moderate.
-    for (int t0 = 0; t0 < n_tasks && r == ncclSuccess; t0 += 64) {
-        if ((r = a->GroupStart()) != ncclSuccess) break;
-        for (int t = t0; t < n_tasks && t < t0 + 64 && r == ncclSuccess; t++) {
-            const int owner = t % comm->world;
-            if (owner == 0 || (comm->rank != 0 && comm->rank != owner)) continue;
-            const int rows = std::min(task_rows, H - t * task_rows);
-            const size_t off = (size_t)t * (size_t)task_rows * (size_t)W, cnt = (size_t)rows * (size_t)W;
-            if (comm->rank == 0) {
-                if (mode == RTW_GATHER_ALL) r = a->Recv((char*)fb->accum + off * 16, cnt * 16, ncclChar, owner, comm->comm, st);
-                if (r == ncclSuccess) r = a->Recv((char*)fb->argb + off * 4, cnt * 4, ncclChar, owner, comm->comm, st);
-            } else {
-                if (mode == RTW_GATHER_ALL) r = a->Send((const char*)fb->accum + off * 16, cnt * 16, ncclChar, 0, comm->comm, st);
-                if (r == ncclSuccess) r = a->Send((const char*)fb->argb + off * 4, cnt * 4, ncclChar, 0, comm->comm, st);
+    if (comm->rank != 0) {
+        if (b.px[0] == 0) return RTW_OK;        // more ranks than tasks: nothing of this rank's to move (the root posts no receive for it either)
+        const hipError_t e = (hipError_t)rtw::launch_gather_rows(false, fb->argb, fb->accum, comm->d_stage, W, task_rows, world, b, with_accum, st);
+        if (e != hipSuccess) return hip_fail(e, "gather pack launch");
+        r = a->Send(comm->d_stage, total, ncclChar, 0, comm->comm, st);
+        comm->messages++;
+    } else {
+        if ((r = a->GroupStart()) == ncclSuccess) {
+            for (int k = 0; k < b.n && r == ncclSuccess; k++) {
+                if (b.px[k] == 0) continue;
+                r = a->Recv((char*)comm->d_stage + b.off[k], rtw::gather_block_bytes(b.px[k], with_accum), ncclChar, b.first_rank + k, comm->comm, st);
+                comm->messages++;
             }
+            const ncclResult_t e = a->GroupEnd();
+            if (r == ncclSuccess) r = e;
         }
-        const ncclResult_t e = a->GroupEnd();
-        if (r == ncclSuccess) r = e;
+        if (r == ncclSuccess) {
+            const hipError_t e = (hipError_t)rtw::launch_gather_rows(true, fb->argb, fb->accum, comm->d_stage, W, task_rows, world, b, with_accum, st);
+            if (e != hipSuccess) return hip_fail(e, "gather unpack launch");
+        }
     }
     if (r != ncclSuccess) return rccl_fail(a, r, "rtw_gather_rows");
     return RTW_OK;
 }
+
+long long rtw_comm_messages(const rtw_comm* comm) { return comm ? comm->messages : 0; }
 
 // ---- stats ------------------------------------------------------------------------------------------------------
 int rtw_stats_enable(rtw_context* ctx, int enabled)

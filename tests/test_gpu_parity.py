@@ -929,6 +929,8 @@ def test_gather_plan_between_ranks_sharing_one_gpu(ctx, tmp_path, world, mode):
             p.kill()
             codes.append(-9)
     assert codes == [0] * world
+    msgs = [int(np.load(out + ".messages%d.npy" % r)[0]) for r in range(world)]
+    assert msgs == [world - 1] + [1] * (world - 1), msgs      # ONE ncclSend per sender, one ncclRecv per peer on the root (round 2: one per 10-row task)
     got = np.load(out)
     W, H, ROWS = 200, 117, 10
     s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Reflective())

@@ -332,3 +332,48 @@ def test_product_sources_under_address_and_ub_sanitizers():
         out, err = p.communicate(timeout=900)
         assert p.returncode == 0 and ("emul ok: %d cases" % len(g)) in out, (g, out[-1500:], err[-3000:])
         assert "runtime error" not in err and "AddressSanitizer" not in err, err[-3000:]
+
+@pytest.mark.parametrize("world,mode,W,H", [(2, "all", 52, 47), (3, "argb", 50, 47), (3, "all", 48, 20)])
+def test_gather_plan_between_ranks_over_the_host_build(tmp_path, oracle_mod, world, mode, W, H):
+    """rtw_gather_rows between real processes WITHOUT a GPU (the N > 1 path on the CPU): every rank is a process running the sanitizer harness's
+    host build of the product (tests/cpu_emul: the same rtwin_capi.cpp, the same pack / unpack kernel under AddressSanitizer), the transport under
+    it is the loopback stand-in for librccl compiled against the same HIP stand-in.  Each rank renders its own 10-row tasks (ragged last task; in
+    the 48 x 20 frame rank 2 of 3 owns no task at all), packs them into ONE block, and rank 0 must end up holding, bit for bit, the oracle's frame:
+    one message per peer (asserted from rtw_comm_messages), accumulators too in mode "all"."""
+    import subprocess
+    import sys
+    here, asan = _sanitizer_build()
+    sup = os.path.join(ROOT, "tests", "support")
+    lib = str(tmp_path / "libloopback_emul.so")
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-O1", "-fPIC", "-shared", "-I" + os.path.join(here, "shim"), os.path.join(sup, "loopback_rccl.cpp"), "-o", lib], check=True)
+    env = dict(os.environ, RTW_LIB=os.path.join(here, "_build", "librtwin_emul.so"), RTW_TEST_EMULATION="1", LD_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               RTW_RCCL_LIBRARY=lib, RTW_LOOPBACK_DIR=str(tmp_path))
+    out = str(tmp_path / "rank0.npz")
+    procs = [subprocess.Popen([sys.executable, os.path.join(sup, "gather_rank.py"), str(r), str(world), mode, out, str(W), str(H)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, (r, o[-1000:], e[-3000:])
+        assert "runtime error" not in e and "AddressSanitizer" not in e, e[-3000:]
+    ROWS = 10
+    n_tasks = (H + ROWS - 1) // ROWS
+    owning = [r for r in range(1, world) if r < n_tasks]
+    msgs = [int(np.load(out + ".messages%d.npy" % r)[0]) for r in range(world)]
+    assert msgs[0] == len(owning) and all(msgs[r] == (1 if r in owning else 0) for r in range(1, world)), msgs      # ONE message per peer
+    O = oracle_mod
+    os_ = O.Scene()
+    sh = os_.add_mesh_obj(asset("TorusKnot.obj"))
+    os_.set_material(sh, [(O.MAT_REFLECTIVE, (1, 1, 1), 0, 0, 0)])
+    ofb = O.Framebuffer(W, H)
+    for p in range(3):
+        os_.render_pass_pool(ofb, 3, False, p, 2, 9, threads=0, task_rows=ROWS)
+    want_accum, want_argb = ofb.read()
+    got = np.load(out)
+    assert (got["argb"] == want_argb).all()
+    ga = got["accum"]
+    if mode == "all":
+        assert (bits(ga) == bits(want_accum)).all()
+    else:
+        mine = (((np.arange(W * H) // W) // ROWS) % world) == 0
+        assert (bits(ga[mine]) == bits(want_accum[mine])).all() and (got["accum"][~mine] == 0).all()
