@@ -14,10 +14,18 @@ after all passes).  Inputs are resident in HBM before the timed region starts.
 
 `--config c5` is BASELINE configs[4] (unitychan, 3840x2160, depth 8; a step = one 4-spp pass of its 16 spp).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the render pass against HBM with SURVEY.md 8(d)'s
-algorithmic bytes (executed tests; the reference-order figure and the rocprof-measured traffic beside
-it); `cpu_baseline` times the reference's CPU path (oracle/_ref, the reference's own sources) or the
-oracle port on the host cores.
+`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset) starts its own N rank processes (python -m
+torch.distributed.run ... bench.py, before this process has touched a GPU), relays rank 0's line and exits with
+their status; launched under torch.distributed.run it is one rank.  With N > 1 and the default config the line also
+carries a `c5` block (BASELINE configs[4]: the frame whose tiles can pay for 8 GPUs; its gather timed separately).
+`--rehearse`: every rank on GPU 0, gloo + a loopback stand-in under rtw_gather_rows -- a check of the N > 1 code path
+on a one-GPU box, not a measurement.
+
+Prints ONE JSON line (rank 0).  `roofline`: the path is LATENCY-bound (bound = "latency"); `frac` is the share of the
+8 TB/s HBM roof that rocprofv3's counters saw (profiles/, stamped with the kernels' hash: printed only when the
+profile was taken on the build being timed), the algorithmic figures of SURVEY.md 8(d) are labelled extras; every
+fraction is computed from `ms_per_step`.  `cpu_baseline` times the reference's CPU path (oracle/_ref, the reference's
+own sources) on the host cores.
 """
 import argparse
 import json
@@ -159,7 +167,7 @@ def cpu_baseline(mesh_path, W, H, spp, depth, kind, rays_per_frame, budget_s=20.
         return cpu_baseline_setup(mesh_path, W, H, spp, depth, rays_per_frame, budget_s)
     cores = O.hw_threads()
     harness = O.REF_HARNESS
-    if os.path.exists(harness) and kind == "diffuse":
+    if os.path.exists(harness):
         with tempfile.TemporaryDirectory() as tmp:
             mp = os.path.join(tmp, "mat.bin")
             O.materials(oracle_material(O, kind)).tofile(mp)
@@ -220,56 +228,153 @@ def rays_through_shape_boxes(scene, W, H, spp):
     return int(hit.sum()) * spp
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--prune", type=int, default=1)
-    ap.add_argument("--pipeline", type=int, default=4)
-    ap.add_argument("--group-max", type=int, default=0, help="passes per group of the pass-batched pipeline (0 = the library's choice)")
-    ap.add_argument("--option", action="append", default=[], help="name=value context option (experiments)")
-    ap.add_argument("--depth", type=int, default=0, help="override the config's depth (experiments only)")
-    ap.add_argument("--gather", default="native", choices=("native", "torch"), help="N>1: rtw_gather_rows (RCCL send/recv out of the framebuffers) or torch.distributed.gather")
-    ap.add_argument("--gather-accum", action="store_true", help="N>1: gather the float accumulator (16 B/pixel) as well as the ARGB image (4 B/pixel); the default moves what "
-                                                              "the reference writes out after its passes, the image")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
+def kernels_sha(R):
+    """hash of the device sources the loaded librtwin.so was built from (rtw_version(): '... kernels <sha>')"""
+    v = R.library().rtw_version().decode()
+    return v.split("kernels ")[1].split(")")[0].strip() if "kernels " in v else None, v
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
 
-    import torch
-    import torch.distributed as dist
-    import raytracerwin_amd as R
+def profile_field(name, sha):
+    """a figure measured under rocprofv3 by tools/profile_round.sh and kept under profiles/: returned only when that profile was taken on the very
+    kernels being timed now (its recorded hash == the loaded library's); else None and the reason"""
+    p = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(p):
+        return None, "no %s" % os.path.relpath(p, ROOT)
+    try:
+        d = json.load(open(p))
+    except Exception as e:
+        return None, "unreadable %s: %r" % (os.path.relpath(p, ROOT), e)
+    if not sha or d.get("kernels_sha") != sha:
+        return None, "%s was taken on kernels %s, this library is %s: not printed" % (os.path.relpath(p, ROOT), d.get("kernels_sha"), sha)
+    return d, "profiles/%s (rocprofv3 run of this build's kernels %s; an earlier run, not this one)" % (name, sha)
 
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
-    # REHEARSAL of the N > 1 code path on a box with ONE GPU (tools/rehearse_multirank.sh): RTW_BENCH_REHEARSE=1 puts every rank on GPU 0, with
-    # gloo for the process group and the loopback stand-in for librccl under rtw_gather_rows (RCCL refuses two ranks on one device).  The line it
-    # prints says so in `rehearsal`; its throughput means nothing (the ranks share one GPU) -- what it checks is that every rank gets through
-    # the bootstrap, the K passes of its tasks, the gather and the verification against the one-GPU replay.
-    rehearse = os.environ.get("RTW_BENCH_REHEARSE", "") == "1"
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE this process touches a GPU (it never does), the way the
+    driver would (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1); relay rank 0's JSON line; exit with the children's status."""
+    import socket
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tmp = None
+    if args.rehearse:
+        tmp = tempfile.mkdtemp(prefix="rtw_rehearse_")
+        lib = os.path.join(tmp, "libloopback_rccl.so")
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "support", "loopback_rccl.cpp"),
+                               "-o", lib, "-L/opt/rocm/lib", "-lamdhip64"])
+        env.update(RTW_RCCL_LIBRARY=lib, RTW_LOOPBACK_DIR=tmp, RTW_BENCH_REHEARSE="1")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--rehearse"]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if tmp:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    if line:
+        print(line, flush=True)
+    sys.exit(rc if rc != 0 else (0 if line else 1))
 
-    mesh, W, H, spp, depth, kind = CONFIGS[args.config]
-    if args.depth > 0:
+
+class Bench:
+    """one rank's device state: context, stream, process group, communicator"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        import raytracerwin_amd as R
+        self.torch, self.dist, self.R, self.args = torch, dist, R, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+        # REHEARSAL of the N > 1 code path on a box with ONE GPU (--rehearse / tools/rehearse_multirank.sh): every rank on GPU 0, gloo for the process group and the
+        # loopback stand-in for librccl under rtw_gather_rows (RCCL refuses two ranks on one device).  The line says so in `rehearsal`; its throughput means nothing.
+        self.rehearse = os.environ.get("RTW_BENCH_REHEARSE", "") == "1"
+        if self.rehearse:
+            local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            sys.exit("bench.py: rank %d has no GPU (%d visible); --rehearse runs every rank on GPU 0" % (self.rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.local_rank = local_rank
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo" if self.rehearse else "nccl", **({} if self.rehearse else {"device_id": self.dev}))
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.ctx = R.Context(local_rank, stream=self.stream.cuda_stream)
+        self.ctx.set_option("pipeline", args.pipeline)
+        if args.group_max > 0:
+            self.ctx.set_option("group_max", args.group_max)
+        for kv in args.option:
+            k, v = kv.split("=")
+            self.ctx.set_option(k, int(v))
+        self.comm, self.gather_kind = None, None
+        if self.world > 1 and args.gather == "native":
+            self.make_comm()
+        elif self.world > 1:
+            self.gather_kind = "torch.distributed.gather with staging copies"
+
+    def make_comm(self):
+        # rank 0's ncclUniqueId to every rank through the process group the launcher set up; every rank takes the same decision at every step, so that a
+        # failure on one of them (librccl not loadable, communicator not created) sends ALL ranks to the torch.distributed gather together
+        torch, dist, R, dev = self.torch, self.dist, self.R, self.dev
+        note = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            try:
+                note[1:] = torch.tensor(list(R.Comm.unique_id()), dtype=torch.uint8, device=dev)
+                note[0] = 1
+            except Exception:
+                note[0] = 0
+        dist.broadcast(note, src=0)
+        made = torch.zeros(1, dtype=torch.int32, device=dev)
+        comm = None
+        if int(note[0].item()) == 1:
+            try:
+                comm = R.Comm(self.ctx, self.rank, self.world, bytes(note[1:].cpu().tolist()))
+                made[0] = 1
+            except Exception:
+                comm = None
+        dist.all_reduce(made, op=dist.ReduceOp.MIN)
+        if int(made.item()) == 1:
+            self.comm = comm
+            self.gather_kind = "rtw_gather_rows: every rank packs its task rows into one block, ONE ncclSend / ncclRecv per peer (RCCL over xGMI), rank 0 unpacks them with one launch"
+        else:
+            if comm is not None:
+                comm.close()
+            self.gather_kind = "torch.distributed.gather with staging copies (the native communicator could not be created on every rank)"
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        if self.comm is not None:
+            self.comm.close()
+        self.ctx.close()
+
+
+def measure(B, cfg, K, Wm, primary):
+    """W warm-up steps, then EXACTLY K steps (ONE rtw_render_passes call; with N > 1 followed by the one gather) between barriers, max over ranks;
+    rank 0 verifies the timed buffers against a pass-by-pass single-kernel replay and returns the block of figures (None on the other ranks).
+    primary: the config the line is about (all extras); else a compact block."""
+    torch, dist, R, args, ctx, dev, stream, rank, world = B.torch, B.dist, B.R, B.args, B.ctx, B.dev, B.stream, B.rank, B.world
+    from raytracerwin_amd import sharding
+    mesh, W, H, spp, depth, kind = CONFIGS[cfg]
+    if args.depth > 0 and primary:
         depth = args.depth
     mesh_path = os.path.join(ROOT, "assets", mesh + ".obj")
     data = "synthetic frame of assets/%s.obj (byte copy of the reference's Data file)" % mesh
@@ -279,14 +384,6 @@ def main():
         data = "synthetic frame of a procedural (2,3) torus knot, 600 vertices / 1200 triangles (asset missing)"
     npix = W * H
 
-    stream = torch.cuda.Stream(device=dev)
-    ctx = R.Context(local_rank, stream=stream.cuda_stream)
-    ctx.set_option("pipeline", args.pipeline)
-    if args.group_max > 0:
-        ctx.set_option("group_max", args.group_max)
-    for kv in args.option:
-        k, v = kv.split("=")
-        ctx.set_option(k, int(v))
     scene = R.RayTracerScene(ctx)
     if kind == "setup":
         from raytracerwin_amd.setup_scene import SetupScene
@@ -302,38 +399,7 @@ def main():
         accum = torch.zeros(npix * 4, dtype=torch.float32, device=dev)
         argb = torch.zeros(npix, dtype=torch.int32, device=dev)
     fb = R.Framebuffer(ctx, W, H, accum.data_ptr(), argb.data_ptr())
-
-    from raytracerwin_amd import sharding
-    comm = None
-    gather_kind = None
-    if world > 1 and args.gather == "native":
-        # rank 0's ncclUniqueId to every rank through the process group the launcher set up; every rank takes the same decision at every step, so
-        # that a failure on one of them (librccl not loadable, communicator not created) sends ALL ranks to the torch.distributed gather together
-        note = torch.zeros(129, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            try:
-                note[1:] = torch.tensor(list(R.Comm.unique_id()), dtype=torch.uint8, device=dev)
-                note[0] = 1
-            except Exception:
-                note[0] = 0
-        dist.broadcast(note, src=0)
-        made = torch.zeros(1, dtype=torch.int32, device=dev)
-        if int(note[0].item()) == 1:
-            try:
-                comm = R.Comm(ctx, rank, world, bytes(note[1:].cpu().tolist()))
-                made[0] = 1
-            except Exception:
-                comm = None
-        dist.all_reduce(made, op=dist.ReduceOp.MIN)
-        if int(made.item()) == 1:
-            gather_kind = "rtw_gather_rows: grouped ncclSend / ncclRecv of every rank's task rows straight out of the framebuffers (RCCL over xGMI)"
-        else:
-            if comm is not None:
-                comm.close()
-            comm = None
-            gather_kind = "torch.distributed.gather with staging copies (the native communicator could not be created on every rank)"
-    elif world > 1:
-        gather_kind = "torch.distributed.gather with staging copies"
+    argb_only = not args.gather_accum
 
     def steps(first, n):
         # n steps = n passes of the reference's sample loop (UpdateBitmapPixels, Src/RayTracerProgram.cpp:317-361) over this rank's
@@ -341,36 +407,30 @@ def main():
         scene.render_passes(fb, TASK_ROWS, rank, world, depth, None, first, n, spp, SEED)
 
     def gather():
-        if comm is not None:
-            comm.gather_rows(fb, TASK_ROWS, (not args.gather_accum))
+        if B.comm is not None:
+            B.comm.gather_rows(fb, TASK_ROWS, argb_only)
         else:
-            bufs = [argb.view(H, W)] if (not args.gather_accum) else [accum.view(H, W * 4), argb.view(H, W)]
+            bufs = [argb.view(H, W)] if argb_only else [accum.view(H, W * 4), argb.view(H, W)]
             sharding.gather_rows(bufs, H, TASK_ROWS, rank, world, dist, dev)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    K, Wm = args.steps, args.warmup
     with torch.cuda.stream(stream):
         t0 = time.perf_counter()
-        steps(0, 1)             # first use of this frame shape: the screen bins and the tile / job tables are built here (host) and uploaded
+        steps(0, 1)             # first use of this frame shape: screen bins, tile / job tables, the workspace of a one-pass group
         torch.cuda.synchronize(dev)
         first_call_ms = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         steps(1, 1)
         torch.cuda.synchronize(dev)
         second_call_ms = (time.perf_counter() - t0) * 1e3
+        scene.render_reserve(fb, TASK_ROWS, rank, world, depth, K, spp)     # the workspace of the K-pass call's groups, outside the timed region
         if Wm > 0:
             steps(2, Wm)
         if world > 1:
-            gather()            # RCCL sets its channels up on first use
-    barrier()
+            gather()            # RCCL sets its channels up on first use; the staging blocks are allocated here
+    B.barrier()
     accum.zero_()
     argb.zero_()
-    barrier()
+    B.barrier()
 
     ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
@@ -381,16 +441,17 @@ def main():
         if world > 1:
             gather()            # the one exchange of the path: every rank's rows to rank 0, once, after the K passes
         ev2.record(stream)
-    barrier()
+    B.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K           # HIP events on the launch stream around the K steps: average render-pass duration
+    render_ms = ev0.elapsed_time(ev1)               # HIP events on the launch stream around the K steps (this rank)
     gather_ms = ev1.elapsed_time(ev2) if world > 1 else None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ms_per_step = elapsed / K * 1e3
 
-    result = None
+    res = None
     if rank == 0:
         final_accum = accum.cpu().numpy().view(np.uint32).reshape(-1, 4).copy()
         final_argb = argb.cpu().numpy().view(np.uint32).copy()
@@ -405,7 +466,7 @@ def main():
         b2 = fb2.resolve_argb()
         ctx.set_option("pipeline", args.pipeline)
         same_argb = bool((b2 == final_argb).all())
-        same_accum = bool((a2.view(np.uint32) == final_accum).all()) if not (world > 1 and (not args.gather_accum)) else None
+        same_accum = bool((a2.view(np.uint32) == final_accum).all()) if not (world > 1 and argb_only) else None
         verified = bool(same_argb and same_accum is not False)
         # ---- work counters of the K timed passes as the timed pipeline runs them (one GPU, same grouping)
         ctx.stats_enable(True)
@@ -413,148 +474,219 @@ def main():
         fb2.clear()
         scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, 0, K, spp, SEED)
         st = ctx.stats()
-        # reference-faithful visit counts (un-pruned DFS order: what KdNode::TestRayIntersection visits) of ONE pass
-        scene.set_prune(0)
-        scene.set_traversal(0)
-        ctx.stats_reset()
-        fb2.clear()
-        R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, 0, spp, SEED)
-        st_ref = ctx.stats()
-        scene.set_prune(args.prune)
-        scene.set_traversal(1)
         ctx.stats_enable(False)
-        # ---- per-stage durations: HIP events recorded by the library on the launch stream around the stages of one group (extra untimed passes)
-        stage_ms = None
-        if args.pipeline >= 3:
-            ctx.set_option("kernel_timing", 1)
-            acc = []
-            for i in range(3):
-                fb2.clear()
-                scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, 0, min(K, 64), spp, SEED)
-                if i > 0:
-                    acc.append(ctx.last_pass_kernel_ms())
-            ctx.set_option("kernel_timing", 0)
-            g = float(max(1, ctx.last_group_passes()))
-            stage_ms = {"passes_in_the_timed_group": int(g), "primary_per_pass": float(np.mean([k[0] for k in acc])) / g,
-                        "bounce_rounds_per_pass": float(np.mean([k[1] for k in acc])) / g, "resolve_per_pass": float(np.mean([k[2] for k in acc])) / g,
-                        "note": "HIP events between the stages of the LAST group of an untimed call (a call's passes are rendered in groups; the group's size follows the paths per pass)"}
+        rays_total, cam_total = st["rays"], st["camera_rays"]
+        res = {"workload": ("RayTracerProgram::SetupScene (4 spheres, capsule, ground plane, %s.obj) %dx%d %d spp depth %d, reference camera "
+                            "(the reference's default scene and window; not a BASELINE config)" % (mesh, W, H, spp, depth)) if kind == "setup" else
+                           "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s]%s)"
+                           % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[cfg],
+                              "; a step is one 4-spp pass, four of them make the config's 16 spp" if cfg == "c5" else ""),
+               "value": rays_total / elapsed / 1e6, "steps": K, "warmup": Wm, "ms_per_step": ms_per_step, "render_ms_per_step_rank0": render_ms / K,
+               "gather_ms": gather_ms, "rays_per_frame": rays_total / K, "camera_Mrays_per_s": cam_total / elapsed / 1e6,
+               "verified": verified, "data": data, "depth": depth, "W": W, "H": H, "spp": spp, "kind": kind, "mesh_path": mesh_path,
+               "commit_ms": commit_ms, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "pipeline_run": ctx.last_pass_pipeline(),
+               "memory_bytes": ctx.memory_bytes() if hasattr(ctx, "memory_bytes") else None}
+        if primary:
+            st_run_pass = {k: v / K for k, v in st.items()}
+            # reference-faithful visit counts (un-pruned DFS order: what KdNode::TestRayIntersection visits) of ONE pass
+            ctx.stats_enable(True)
+            scene.set_prune(0)
+            scene.set_traversal(0)
+            ctx.stats_reset()
+            fb2.clear()
+            R.ThreadWorker_Render(scene, fb2, 0, npix - 1, depth, None, 0, spp, SEED)
+            st_ref = ctx.stats()
+            scene.set_prune(args.prune)
+            scene.set_traversal(1)
+            ctx.stats_enable(False)
+            # ---- a frame that can be SHOWN after every pass (the reference's window blits bitcolor[] as the passes come, Src/RayTracerProgram.cpp:184-185,346-360):
+            # separate rtw_render_passes calls of ONE pass each, launch-size hints primed, each between two HIP events on the launch stream
+            single = None
+            if world == 1:
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+                with torch.cuda.stream(stream):
+                    for i in range(4):
+                        scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, K + i, 1, spp, SEED)
+                    torch.cuda.synchronize(dev)
+                    for i in range(20):
+                        evs[i].record(stream)
+                        scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, K + 4 + i, 1, spp, SEED)
+                    evs[20].record(stream)
+                torch.cuda.synchronize(dev)
+                per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))
+                single = {"median": per[10], "min": per[0], "max": per[-1], "calls": 20}
+            # ---- per-stage durations: HIP events recorded by the library on the launch stream around the stages of one group (extra untimed passes)
+            stage_ms = None
+            if args.pipeline >= 3:
+                ctx.set_option("kernel_timing", 1)
+                acc = []
+                for i in range(3):
+                    fb2.clear()
+                    scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, 0, min(K, 64), spp, SEED)
+                    if i > 0:
+                        acc.append(ctx.last_pass_kernel_ms())
+                ctx.set_option("kernel_timing", 0)
+                g = float(max(1, ctx.last_group_passes()))
+                stage_ms = {"passes_in_the_timed_group": int(g), "primary_per_pass": float(np.mean([k[0] for k in acc])) / g,
+                            "bounce_rounds_per_pass": float(np.mean([k[1] for k in acc])) / g, "resolve_per_pass": float(np.mean([k[2] for k in acc])) / g,
+                            "note": "HIP events between the stages of the LAST group of an untimed call (a call's passes are rendered in groups; the group's size follows the paths per pass; "
+                                    "timed groups are not split into two halves)"}
+            # ---- host vs device construction of the tree / layouts / screen bins (untimed; two fresh scenes)
+            build_ms = {}
+            for label, dev_build in (("device", 1), ("host", 0), ("device", 1), ("host", 0)):       # twice each, alternating; the faster run of each is kept
+                ctx.set_option("device_build", dev_build)
+                sc2 = R.RayTracerScene(ctx)
+                if kind == "setup":
+                    from raytracerwin_amd.setup_scene import SetupScene
+                    SetupScene(sc2, mesh_path)
+                else:
+                    sc2.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
+                t0 = time.perf_counter()
+                sc2.commit()
+                t1 = time.perf_counter()
+                sc2.mesh_bins(W, H, 16, 4, shape=sc2.n_shapes - 1)
+                t2 = time.perf_counter()
+                got = {"commit_ms": (t1 - t0) * 1e3, "screen_bins_ms": (t2 - t1) * 1e3}
+                build_ms[label] = got if label not in build_ms else {k: min(got[k], build_ms[label][k]) for k in got}
+                sc2.close()
+            ctx.set_option("device_build", 1)
+            nontrivial_cam = rays_through_shape_boxes(scene, W, H, spp)
+            res.update(st_run_pass=st_run_pass, st_ref=st_ref, single=single, stage_ms=stage_ms, build_ms=build_ms, nontrivial_cam=nontrivial_cam,
+                       nontrivial=nontrivial_cam * K + (rays_total - cam_total))          # every secondary ray starts on a surface, inside its shape's box
         fb2.close()
-        # ---- host vs device construction of the tree / layouts / screen bins (untimed; two fresh scenes)
-        build_ms = {}
-        for label, dev_build in (("device", 1), ("host", 0), ("device", 1), ("host", 0)):       # twice each, alternating; the faster run of each is kept
-            ctx.set_option("device_build", dev_build)
-            sc2 = R.RayTracerScene(ctx)
-            if kind == "setup":
-                from raytracerwin_amd.setup_scene import SetupScene
-                SetupScene(sc2, mesh_path)
-            else:
-                sc2.AddShape(R.RMeshShape.Create(mesh_path), make_material(R, kind))
-            t0 = time.perf_counter()
-            sc2.commit()
-            t1 = time.perf_counter()
-            sc2.mesh_bins(W, H, 16, 4, shape=sc2.n_shapes - 1)
-            t2 = time.perf_counter()
-            got = {"commit_ms": (t1 - t0) * 1e3, "screen_bins_ms": (t2 - t1) * 1e3}
-            build_ms[label] = got if label not in build_ms else {k: min(got[k], build_ms[label][k]) for k in got}
-            sc2.close()
-        ctx.set_option("device_build", 1)
-
-        rays_total = st["rays"]
-        value = rays_total / elapsed / 1e6
-        cam_total = st["camera_rays"]
-        nontrivial_cam = rays_through_shape_boxes(scene, W, H, spp)
-        nontrivial = nontrivial_cam * K + (rays_total - cam_total)          # every secondary ray starts on a surface, inside its shape's box
-        st_run_pass = {k: v / K for k, v in st.items()}
-        # bytes per pass: SURVEY.md 8(d)'s weights on (a) the visits the reference's un-pruned walk makes, (b) the tests the timed kernels execute
-        alg_ref = algorithmic_bytes(st_ref, npix)
-        alg_run = algorithmic_bytes(st_run_pass, npix)
-        pass_ms = kernel_ms
-        traffic = None
-        valu_per_pass = None        # wave-level VALU instructions per pass from the kept PMC summary of this config (SQ_INSTS_VALU, own rocprofv3 run)
-        ip = os.path.join(ROOT, "profiles", "r02_%s_insts.json" % args.config)
-        if args.pipeline == 4 and os.path.exists(ip):
-            try:
-                ins = json.load(open(ip))
-                valu_per_pass = sum(v["SQ_INSTS_VALU"] for v in ins["per_kernel_in_the_timed_call"].values()) / float(ins.get("steps_in_the_timed_call", 20))
-            except Exception:
-                valu_per_pass = None
-        tp = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % args.config)
-        if os.path.exists(tp) and world == 1:
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_pass")
-            except Exception:
-                traffic = None
-        achieved = alg_run / world / (pass_ms * 1e-3) / 1e9
-        result = {
-            "metric": "Mrays/s (rays = closest-hit scene queries, primary + secondary) at %dx%d depth %d" % (W, H, depth),
-            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": data,
-            "config": {"workload": ("RayTracerProgram::SetupScene (4 spheres, capsule, ground plane, %s.obj) %dx%d %d spp depth %d, reference camera "
-                                    "(the reference's default scene and window; not a BASELINE config)" % (mesh, W, H, spp, depth)) if kind == "setup" else
-                                   "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s]%s)"
-                                   % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[args.config],
-                                      "; a step is one 4-spp pass, four of them make the config's 16 spp" if args.config == "c5" else ""),
-                       "step": "one pass of the reference's sample loop over the whole frame; the K steps are ONE rtw_render_passes call, whose passes are rendered in "
-                               "groups that share one set of launches (every pixel's accumulate + ARGB resolve still runs once per pass, in pass order)",
-                       "sharding": "10-row tasks round-robin over ranks, one gather of the rows to rank 0 after the K passes",
-                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "pipeline_run": ctx.last_pass_pipeline()},
-            "camera_Mrays_per_s": cam_total / elapsed / 1e6,
-            "nontrivial_Mrays_per_s": nontrivial / elapsed / 1e6,
-            "nontrivial_rays_note": "rays that meet a shape's culling box: camera rays by pixel-centre direction (%d of %d per pass) + all secondary rays" % (nontrivial_cam, npix * spp),
-            "rays_per_frame": rays_total / K,
-            "verified_bit_identical_to_single_kernel_replay": verified,
-            "scene_commit_ms": commit_ms,
-            "bins_and_tables_build_ms": max(0.0, first_call_ms - second_call_ms),
-            "tree_and_bins_build_ms": build_ms,
-            "host_setup_note": "scene_commit_ms = tree build (on the device by default, the reference's split decisions) + derived layouts + upload / read-back; bins_and_tables_build_ms = "
-                               "first render call of this frame shape minus the second (screen bins on the device, busy / sky tile lists and job table on the host, the two group workspaces' hipMalloc); "
-                               "tree_and_bins_build_ms times both constructions, device and host, on fresh scenes (two runs each, alternating, the faster kept; commit_ms includes the texture atlas upload, the same either way); none of it is in the timed region",
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "frac_algorithmic": achieved / HBM_PEAK_GBS,
-                         "frac_hbm_measured": (traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "frac_algorithmic_reference_order": alg_ref / world / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_note": "frac / frac_algorithmic can exceed 1: SURVEY.md 8(d)'s bytes are what an implementation that fetched every record from memory would move; "
-                                      "here the tree is staged in LDS and the records come out of L2 / Infinity Cache, so the HBM roof does not bind (frac_hbm_measured is the "
-                                      "share of 8 TB/s actually used)",
-                         "valu_issue_frac": (valu_per_pass * 2.0 / (256 * 4) / 2.4e9 / (pass_ms * 1e-3)) if valu_per_pass else None,
-                         "valu_issue_note": "wave-level VALU instructions per pass (profiles/r02_<cfg>_insts.json) x 2 cycles (a wave64 instruction on a SIMD-32) / (256 CUs x 4 SIMDs x "
-                                            "2.4 GHz) / pass time: the other roof of this path, also far away",
-                         "limiter": "latency, not a throughput roof: HBM carries a tenth of its peak (the tree, bins and triangle records stay in LDS / L2 / Infinity Cache) and the "
-                                    "vector units issue about a third of theirs; a ray's walk is a chain of dependent steps (node record from LDS -> box test -> next index) on 3-4 waves "
-                                    "per SIMD, a launch lasts as long as its slowest wave, and shading gathers scattered path records",
-                         "bytes_model": "SURVEY.md 8(d): 32 B/box test + 48 B/triangle test + 64 B/shaded hit + 16 B/texture sample + 36 B/pixel-pass; `achieved` prices the tests the "
-                                        "timed kernels EXECUTE (bins and pruning provably skip visits the reference makes and rejects); frac_algorithmic_reference_order prices the "
-                                        "reference's own un-pruned visit list and can exceed 1 for that reason",
-                         "kernel": "render pass = 1/K of a group: gprimary (+ gsky beside it) + per-bounce gtrace / gshade rounds + gresolve (rtw_group_kernels.h)" if args.pipeline == 4
-                                   else "render pass (one rtw_render_tasks call)",
-                         "kernel_ms": pass_ms,
-                         "stage_ms": stage_ms,
-                         "algorithmic_bytes_per_pass_executed": alg_run,
-                         "algorithmic_bytes_per_pass_reference_order": alg_ref,
-                         "counters_per_pass_reference_order": st_ref, "counters_per_pass_as_run": st_run_pass},
-        }
-        if rehearse:
-            result["rehearsal"] = "RTW_BENCH_REHEARSE=1: all %d ranks on GPU 0, gloo process group, loopback transport under rtw_gather_rows -- a check of the code path, not a measurement" % world
-        if world > 1:
-            result["gather_ms"] = gather_ms
-            result["gather"] = gather_kind + ("; ARGB only" if (not args.gather_accum) else "; accumulator + ARGB")
-            result["gather_verified_bit_identical_to_1gpu"] = verified
-        if world == 1 and not args.no_cpu:
-            try:
-                result["cpu_baseline"] = cpu_baseline(mesh_path, W, H, spp, depth, kind, rays_total / K, args.cpu_budget)
-            except Exception as e:      # the baseline is a reported extra, never the thing measured
-                result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if comm is not None:
-        comm.close()
     fb.close()
     scene.close()
-    ctx.close()
+    del accum, argb
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--prune", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=4)
+    ap.add_argument("--group-max", type=int, default=0, help="passes per group of the pass-batched pipeline (0 = the library's choice)")
+    ap.add_argument("--option", action="append", default=[], help="name=value context option (experiments)")
+    ap.add_argument("--depth", type=int, default=0, help="override the config's depth (experiments only)")
+    ap.add_argument("--gather", default="native", choices=("native", "torch"), help="N>1: rtw_gather_rows (one RCCL message per peer) or torch.distributed.gather")
+    ap.add_argument("--gather-accum", action="store_true", help="N>1: gather the float accumulator (16 B/pixel) as well as the ARGB image (4 B/pixel); the default moves what "
+                                                              "the reference writes out after its passes, the image")
+    ap.add_argument("--no-c5", action="store_true", help="N>1 with the default config: leave out the `c5` block")
+    ap.add_argument("--rehearse", action="store_true", help="N>1 on a ONE-GPU box: every rank on GPU 0, gloo + loopback transport (a check of the code path, not a measurement)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)       # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        args.gpus = world
+
+    B = Bench(args)
+    R, rank = B.R, B.rank
+    K, Wm = args.steps, args.warmup
+    m = measure(B, args.config, K, Wm, True)
+    c5 = None
+    if world > 1 and args.config == "c2" and not args.no_c5:
+        k5 = 4 * max(1, min(K, 8) // 4)             # whole 16-spp frames (four 4-spp passes each)
+        c5 = measure(B, "c5", k5, min(Wm, 4), False)
+
+    if rank == 0:
+        sha, version = kernels_sha(R)
+        npix, spp, depth = m["W"] * m["H"], m["spp"], m["depth"]
+        ms = m["ms_per_step"]
+        sec = ms * 1e-3
+        # bytes per pass: SURVEY.md 8(d)'s weights on (a) the visits the reference's un-pruned walk makes, (b) the tests the timed kernels execute.
+        # The framebuffer term as EXECUTED: a group of passes reads and writes a pixel's accumulator once and stores its ARGB word once (the per-pass
+        # accumulate / divide / gamma arithmetic stays in registers), so 36 B per pixel and GROUP, i.e. 36 / passes-per-group per pixel-pass
+        group = max(1, B.ctx.last_group_passes()) if args.pipeline == 4 else 1
+        group = min(group, K)
+        alg_ref = algorithmic_bytes(m["st_ref"], npix)
+        alg_run = algorithmic_bytes(m["st_run_pass"], npix / float(group))
+        tr, tr_src = profile_field("r03_traffic_%s.json" % args.config, sha) if world == 1 else (None, "N > 1: no per-rank profile")
+        ins, ins_src = profile_field("r03_%s_insts.json" % args.config, sha) if world == 1 else (None, "N > 1: no per-rank profile")
+        traffic = tr.get("hbm_bytes_per_pass") if tr else None
+        valu_per_pass = ins.get("valu_instructions_per_pass") if ins else None
+        hbm_gbs = (traffic / sec / 1e9) if traffic else None
+        result = {
+            "metric": "Mrays/s (rays = closest-hit scene queries, primary + secondary) at %dx%d depth %d" % (m["W"], m["H"], depth),
+            "value": m["value"], "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": m["data"],
+            "config": {"workload": m["workload"],
+                       "step": "one pass of the reference's sample loop over the whole frame; the K steps are ONE rtw_render_passes call, whose passes are rendered in groups "
+                               "that share one set of launches: every pixel's per-pass colour, accumulate, divide and gamma run once per pass in pass order, in registers; "
+                               "its accumulator entry and ARGB word are WRITTEN once per group -- intermediate images are not materialised inside a call (single_pass_ms is "
+                               "the rate at which a caller can show every pass)",
+                       "sharding": "10-row tasks round-robin over ranks, one gather of the rows to rank 0 after the K passes",
+                       "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "pipeline_run": m["pipeline_run"], "passes_per_group": group},
+            "library": version,
+            "camera_Mrays_per_s": m["camera_Mrays_per_s"],
+            "nontrivial_Mrays_per_s": m["nontrivial"] / (ms * K * 1e-3) / 1e6,
+            "nontrivial_rays_note": "rays that meet a shape's culling box: camera rays by pixel-centre direction (%d of %d per pass) + all secondary rays" % (m["nontrivial_cam"], npix * spp),
+            "rays_per_frame": m["rays_per_frame"],
+            "verified_bit_identical_to_single_kernel_replay": m["verified"],
+            "single_pass_ms": m["single"]["median"] if m["single"] else None,
+            "single_pass_note": ("median of 20 separate rtw_render_passes(n = 1) calls (min %.4f, max %.4f ms; HIP events around each call; launch-size hints primed by 4 such calls): "
+                                 "a frame that can be shown after EVERY pass, as the reference's window does" % (m["single"]["min"], m["single"]["max"])) if m["single"] else None,
+            "cold_first_call_ms": m["first_call_ms"],
+            "cold_first_call_note": "wall clock of the first one-pass call on this frame shape (screen bins built on the device, tile / job tables, workspace hipMalloc); the second such call: %.3f ms" % m["second_call_ms"],
+            "device_memory_bytes": m["memory_bytes"],
+            "scene_commit_ms": m["commit_ms"],
+            "bins_and_tables_build_ms": max(0.0, m["first_call_ms"] - m["second_call_ms"]),
+            "tree_and_bins_build_ms": m["build_ms"],
+            "host_setup_note": "scene_commit_ms = tree build (on the device by default, the reference's split decisions) + derived layouts + upload / read-back; bins_and_tables_build_ms = "
+                               "first render call of this frame shape minus the second; tree_and_bins_build_ms times both constructions, device and host, on fresh scenes (two runs each, "
+                               "alternating, the faster kept; commit_ms includes the texture atlas upload, the same either way); none of it is in the timed region",
+            "roofline": {"bound": "latency",
+                         "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
+                         "achieved_note": "HBM bytes per pass that rocprofv3's FETCH_SIZE / WRITE_SIZE counted (`traffic`) / ms_per_step: the rocprof-evidenced share of the 8 TB/s roof; "
+                                          "null when no profile of THIS build's kernels is on file",
+                         "traffic": traffic, "traffic_source": tr_src,
+                         "frac_algorithmic_executed": alg_run / world / sec / 1e9 / HBM_PEAK_GBS,
+                         "frac_algorithmic_reference_order": alg_ref / world / sec / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_note": "SURVEY.md 8(d)'s model -- 32 B/box test + 48 B/triangle test + 64 B/shaded hit + 16 B/texture sample + 36 B per pixel and GROUP of passes (the framebuffer "
+                                             "traffic as executed) -- prices every record as if fetched from HBM; here the tree is staged in LDS and the records come out of L2 / Infinity "
+                                             "Cache, so these are NOT HBM fractions: `executed` counts the tests the timed kernels run, `reference_order` the reference's own un-pruned visit "
+                                             "list (bins and pruning provably skip visits the reference makes and rejects), and either can exceed 1",
+                         "valu_issue_frac": (valu_per_pass * 2.0 / (256 * 4) / 2.4e9 / sec) if valu_per_pass else None,
+                         "valu_issue_source": ins_src,
+                         "valu_issue_note": "wave-level VALU instructions per pass (SQ_INSTS_VALU) x 2 cycles (a wave64 instruction on a SIMD-32) / (256 CUs x 4 SIMDs x 2.4 GHz) / ms_per_step",
+                         "trace_kernels_valu_per_secondary_ray": ins.get("trace_kernels_valu_instructions_per_secondary_ray") if ins else None,
+                         "limiter": "latency, not a throughput roof: HBM carries about a tenth of its peak (the tree, bins and triangle records stay in LDS / L2 / Infinity Cache) and the "
+                                    "vector units issue well under their peak; a ray's walk is a chain of dependent steps (node record from LDS -> box test -> next index), a launch lasts "
+                                    "as long as its slowest wave, and shading gathers scattered path records",
+                         "kernel": "render pass = 1/K of a group: gprimary (+ gsky beside it) + per-bounce gtrace / gshade rounds + gresolve (rtw_group_kernels.h)" if args.pipeline == 4
+                                   else "render pass (one rtw_render_tasks call)",
+                         "kernel_ms": m["render_ms_per_step_rank0"],
+                         "stage_ms": m["stage_ms"],
+                         "algorithmic_bytes_per_pass_executed": alg_run,
+                         "algorithmic_bytes_per_pass_reference_order": alg_ref,
+                         "counters_per_pass_reference_order": m["st_ref"], "counters_per_pass_as_run": m["st_run_pass"]},
+        }
+        if B.rehearse:
+            result["rehearsal"] = "RTW_BENCH_REHEARSE=1: all %d ranks on GPU 0, gloo process group, loopback transport under rtw_gather_rows -- a check of the code path, not a measurement" % world
+        if world > 1:
+            result["gather_ms"] = m["gather_ms"]
+            result["gather"] = B.gather_kind + ("; ARGB only" if not args.gather_accum else "; accumulator + ARGB")
+            result["gather_verified_bit_identical_to_1gpu"] = m["verified"]
+            if c5 is not None:
+                result["c5"] = {"workload": c5["workload"], "value": c5["value"], "unit": "Mrays/s", "steps": c5["steps"], "warmup": c5["warmup"], "ms_per_step": c5["ms_per_step"],
+                                "render_ms_per_step_rank0": c5["render_ms_per_step_rank0"], "gather_ms": c5["gather_ms"], "rays_per_frame": c5["rays_per_frame"],
+                                "camera_Mrays_per_s": c5["camera_Mrays_per_s"], "gather_verified_bit_identical_to_1gpu": c5["verified"], "scaling": "strong",
+                                "note": "the same ranks, the same timing rules (barrier + synchronize on both sides, max over ranks), %d steps = %d frame(s) of 16 spp; C2's per-rank share is "
+                                        "small against each launch's latency floor, this is the frame whose tiles can pay" % (c5["steps"], c5["steps"] // 4)}
+        if world == 1 and not args.no_cpu:
+            try:
+                result["cpu_baseline"] = cpu_baseline(m["mesh_path"], m["W"], m["H"], spp, depth, m["kind"], m["rays_per_frame"], args.cpu_budget)
+            except Exception as e:      # the baseline is a reported extra, never the thing measured
+                result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(result), flush=True)
+    B.close()
 
 
 if __name__ == "__main__":

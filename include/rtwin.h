@@ -229,6 +229,21 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                       int max_bounce, int use_base_color, int first_pass, int n_passes,
                       int sub_samples, uint32_t seed);
 
+/* Prepare, without rendering, everything a later rtw_render_passes call with these arguments would otherwise make inside it: the screen bins and tile
+ * tables of this frame shape and the workspace of the largest group of passes that call will form (the workspace is grow-only; growing it waits for the
+ * context's streams -- measured 0.3 ms inside a timed call).  UpdateBitmapPixels has no counterpart: its buffers are static arrays. */
+int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
+                       int max_bounce, int n_passes, int sub_samples);
+/* Device memory the context holds: workspaces + its share of the 201 MB unit-vector table (one copy per device, shared by the contexts on it).
+ * The workspace is sized by the largest group of passes rendered (or reserved) so far: per path slot 116 B + 48 B x max_bounce, slots = pixels of the
+ * frame's busy tiles x sub-samples x passes per group (rounded up to a power of two); e.g. TorusKnot 1080p depth 4: 21 MB for one pass per call,
+ * 0.68 GB for a 20-pass call.  When the device has no room for a group's workspace (or it exceeds the option "workspace_limit_mb"), the call renders
+ * the same image in smaller groups instead of failing (rtw_context_fallbacks counts how often).  rtw_context_trim gives the workspaces back. */
+long long rtw_context_memory_bytes(const rtw_context* ctx);
+long long rtw_context_workspace_bytes(const rtw_context* ctx);
+int rtw_context_trim(rtw_context* ctx);
+int rtw_context_fallbacks(const rtw_context* ctx);
+
 /* ---- multi-GPU: the one exchange of the path.  Every rank renders its own tasks (rtw_render_tasks / rtw_render_passes with rank, world)
  * into a full-size framebuffer; rtw_gather_rows then moves every rank's rows to rank 0 over RCCL (xGMI): one ncclSend / ncclRecv
  * per peer of a compact block of the rank's rows, on the context's stream.  No reference counterpart (the

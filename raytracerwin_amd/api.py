@@ -288,6 +288,23 @@ class Context:
         """the pipeline the latest render call actually ran (a fallback shows here)"""
         return int(library().rtw_last_pass_pipeline(self.h))
 
+    def memory_bytes(self):
+        """device memory the context holds (workspaces + its share of the unit-vector table)"""
+        L = library()
+        L.rtw_context_memory_bytes.restype = C.c_longlong
+        return int(L.rtw_context_memory_bytes(self.h))
+
+    def workspace_bytes(self):
+        L = library()
+        L.rtw_context_workspace_bytes.restype = C.c_longlong
+        return int(L.rtw_context_workspace_bytes(self.h))
+
+    def trim(self):
+        _check(library().rtw_context_trim(self.h))
+
+    def fallbacks(self):
+        return int(library().rtw_context_fallbacks(self.h))
+
     def stats_enable(self, on=True):
         _check(library().rtw_stats_enable(self.h, int(on)))
 
@@ -551,6 +568,11 @@ class RayTracerScene:
         _check(library().rtw_render_passes(self.h, fb.h, int(task_rows), int(rank), int(world), int(MaxBounceCount),
                                            int(opt.UseBaseColor), int(first_pass), int(n_passes), int(sub_samples),
                                            C.c_uint32(seed)))
+
+    def render_reserve(self, fb, task_rows, rank, world, MaxBounceCount, n_passes, sub_samples=4):
+        """rtw_render_reserve: bins, tile tables and workspace of a later render_passes call with these arguments (renders nothing)"""
+        self.commit()
+        _check(library().rtw_render_reserve(self.h, fb.h, int(task_rows), int(rank), int(world), int(MaxBounceCount), int(n_passes), int(sub_samples)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -55,6 +55,31 @@ const std::vector<float>& host_unit_table()
     return g_unit_table;
 }
 
+// device copy of the table: ONE per (process, device), shared by the contexts on that device (201 MB: a second context costs nothing)
+struct DeviceTable { float* d = nullptr; int users = 0; };
+std::map<int, DeviceTable> g_device_tables;
+hipError_t acquire_device_table(int device, float** out)
+{
+    const std::vector<float>& tab = host_unit_table();
+    std::lock_guard<std::mutex> l(g_table_mutex);
+    DeviceTable& t = g_device_tables[device];
+    if (!t.d) {
+        hipError_t e = hipMalloc((void**)&t.d, tab.size() * sizeof(float));
+        if (e != hipSuccess) { t.d = nullptr; return e; }
+        e = hipMemcpy(t.d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(t.d); t.d = nullptr; return e; }
+    }
+    t.users++;
+    *out = t.d;
+    return hipSuccess;
+}
+void release_device_table(int device)
+{
+    std::lock_guard<std::mutex> l(g_table_mutex);
+    DeviceTable& t = g_device_tables[device];
+    if (t.users > 0 && --t.users == 0 && t.d) { (void)hipFree(t.d); t.d = nullptr; }
+}
+
 }  // namespace
 
 struct rtw_context {
@@ -157,6 +182,10 @@ struct rtw_context {
     int trace_persist = 1;              // one-mesh scenes: persistent trace waves that refill their lanes
     int trace_stage = 1;                // the ray-per-lane trace kernel stages the first mesh's upper tree levels in LDS (1024-thread blocks)
     int last_pipeline = -1;             // the pipeline the latest render call actually ran (rtw_last_pass_pipeline)
+    size_t workspace_limit = (size_t)24 << 30;  // a group's workspace may not exceed this (option "workspace_limit_mb"); hipMalloc failing counts as exceeding it
+    bool ws_refused = false;            // the latest ensure_group_workspace was refused (limit or out of memory): the caller retries with a smaller group
+    int group_cap = 0;                  // > 0: groups of the current rtw_render_passes call hold at most this many passes (set after a refusal)
+    int fallbacks = 0;                  // how many times a group was re-formed smaller after a refusal (rtw_context_memory_bytes' caller can see it: option-free diagnostics)
 };
 
 struct rtw_scene {
@@ -224,9 +253,12 @@ extern "C" {
 
 const char* rtw_last_error(void) { return t_error.c_str(); }
 #ifdef HIPEMU_COMPUTE_UNITS      /* defined by tests/cpu_emul's stand-in for the HIP headers: this is the host build the sanitizers run, not the product */
-const char* rtw_version(void) { return "rtwin 0.1 (HOST EMULATION for sanitizer runs -- not the product)"; }
+const char* rtw_version(void) { return "rtwin 0.3 (HOST EMULATION for sanitizer runs -- not the product)"; }
 #else
-const char* rtw_version(void) { return "rtwin 0.1 (gfx950)"; }
+#ifndef RTW_KERNELS_SHA
+#define RTW_KERNELS_SHA "unknown"
+#endif
+const char* rtw_version(void) { return "rtwin 0.3 (gfx950; kernels " RTW_KERNELS_SHA ")"; }      // the hash of the device sources + flags (csrc/Makefile)
 #endif
 
 int rtw_context_create(int device_index, rtw_context** out)
@@ -243,9 +275,7 @@ int rtw_context_create(int device_index, rtw_context** out)
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_index) == hipSuccess && cus > 0) c->cu_count = cus; }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    const std::vector<float>& tab = host_unit_table();
-    HIP_TRY(hipMalloc((void**)&c->d_unit, tab.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(c->d_unit, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(acquire_device_table(device_index, &c->d_unit));
     float thr[256], lut[256];
     rtw::gamma_thresholds(thr);
     rtw::texel_lut(lut);
@@ -283,7 +313,8 @@ int rtw_context_destroy(rtw_context* ctx)
     if (!ctx) return RTW_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->d_unit); (void)hipFree(ctx->d_workspace); (void)hipFree(ctx->d_gamma); (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_stats);
+    if (ctx->d_unit) release_device_table(ctx->device);
+    (void)hipFree(ctx->d_workspace); (void)hipFree(ctx->d_gamma); (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_stats);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pass_graph.exec) (void)hipGraphExecDestroy(ctx->pass_graph.exec);
     if (ctx->pass_graph.graph) (void)hipGraphDestroy(ctx->pass_graph.graph);
@@ -325,6 +356,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
         return RTW_OK;
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "workspace_limit_mb") == 0) { ctx->workspace_limit = value <= 0 ? ((size_t)24 << 30) : ((size_t)value << 20); return RTW_OK; }
     if (std::strcmp(name, "group_split") == 0) { ctx->group_split = value != 0; return RTW_OK; }
     if (std::strcmp(name, "split_paths") == 0) { ctx->split_paths = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "split_min") == 0) { ctx->split_min = value < 2 ? 2 : value; return RTW_OK; }
@@ -1199,13 +1231,21 @@ static int ensure_group_workspace(rtw_context* cx, size_t bytes)
 {
     void*& ws = cx->lane ? cx->d_group_ws2 : cx->d_group_ws;
     size_t& have = cx->lane ? cx->group_ws2_bytes : cx->group_ws_bytes;
+    cx->ws_refused = false;
     if (bytes <= have) return RTW_OK;
+    if (bytes > cx->workspace_limit) { cx->ws_refused = true; return fail(RTW_ERR_HIP, "group workspace above the context's workspace limit"); }
+    // grow-only; growing waits for the streams (rtw_render_reserve does it ahead of a call that must not stall)
     HIP_TRY(hipStreamSynchronize(cx->stream));
     if (cx->aux_stream) HIP_TRY(hipStreamSynchronize(cx->aux_stream));
     if (cx->stream2) HIP_TRY(hipStreamSynchronize(cx->stream2));
     if (ws) { (void)hipFree(ws); ws = nullptr; have = 0; }
     (cx->lane ? cx->group_clean2 : cx->group_clean) = false;
-    HIP_TRY(hipMalloc(&ws, bytes));
+    const hipError_t e = hipMalloc(&ws, bytes);
+    if (e != hipSuccess) {      // no room on the device (a GPU shared with torch, other ranks ...): the caller forms a smaller group
+        ws = nullptr; (void)hipGetLastError();
+        cx->ws_refused = true;
+        return hip_fail(e, "hipMalloc of the group workspace");
+    }
     have = bytes;
     return RTW_OK;
 }
@@ -1239,6 +1279,46 @@ static int group_passes(const rtw_context* cx, long long paths_per_pass, int rem
     }
     if (k < remaining && remaining < 2 * k) k = (remaining + 1) / 2;      // 20 passes at 16 per group: 10 + 10, not 16 + 4 (a small last group pays every launch's latency for little work)
     return (int)(k < remaining ? k : remaining);
+}
+
+// The next group of a call: how many of the `remaining` passes it takes (the policy above, under the cap a refusal of workspace has set) and whether it
+// runs as two halves on two streams.
+static int next_group(const rtw_context* cx, long long per_pass, int remaining, int max_bounce, bool carry, bool preview, bool* split)
+{
+    *split = false;
+    if (preview) return 1;
+    int k = group_passes(cx, per_pass > 0 ? per_pass : 1, remaining, max_bounce, carry);
+    if (cx->group_cap > 0 && k > cx->group_cap) k = cx->group_cap;
+    *split = cx->group_split && k >= cx->split_min && per_pass * (k / 2) >= cx->split_paths && !cx->stats_enabled && !cx->kernel_timing && cx->stream2 != nullptr;
+    return k;
+}
+
+// what rtw_render_passes and rtw_render_reserve share: the rank's share of the frame and its paths per pass (busy tiles x 64 x sub-samples; builds the
+// screen bins and tile tables of this frame shape on first use)
+struct GroupCall { RtwRenderParams p; long long per_pass; };
+static int plan_group_call(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world, int max_bounce, int first_pass, int sub_samples, GroupCall* out)
+{
+    rtw_context* cx = scene->ctx;
+    if (task_rows < 1 || world < 1 || rank < 0 || rank >= world) return fail(RTW_ERR_INVALID, "bad task partition");
+    int rc = check_render_args(scene, fb, max_bounce, first_pass, sub_samples); if (rc != RTW_OK) return rc;
+    RtwRenderParams p; std::memset(&p, 0, sizeof p);
+    const int n_tasks = (fb->height + task_rows - 1) / task_rows;
+    const int mine = n_tasks > rank ? (n_tasks - rank + world - 1) / world : 0;
+    p.begin = 0; p.task_rows = task_rows; p.rank = rank; p.world = world;
+    const int64_t cnt = world == 1 ? (int64_t)fb->width * fb->height : (int64_t)mine * task_rows * fb->width;
+    if (cnt > INT32_MAX) return fail(RTW_ERR_LIMIT, "too many work items");
+    p.count = (int)cnt;
+    out->p = p;
+    // paths per pass: the busy tiles' pixels x sub-samples (known once the tile lists exist; the whole share until then)
+    long long per_pass = (long long)p.count * sub_samples;
+    if (p.count > 0) {
+        RtwRenderParams t = p; t.width = fb->width; t.height = fb->height;
+        rtw_scene::BinSet* bs = nullptr; const rtw_scene::GroupTable* gt = nullptr;
+        if (!cx->stats_enabled && choose_group_tiles(t, 0, fb->width * fb->height - 1) && scene_bins(scene, t.width, t.height, t.tile_w, t.tile_h, &bs) == RTW_OK &&
+            scene_group_table(scene, *bs, t, sub_samples, &gt) == RTW_OK && gt) per_pass = (long long)gt->n_busy * 64 * sub_samples;
+    }
+    out->per_pass = per_pass;
+    return RTW_OK;
 }
 
 // One group: passes first_pass .. first_pass + n_passes - 1 over the pixels begin .. end of this rank's share of the frame.
@@ -1277,20 +1357,8 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     const bool carry = scene->texture_carry;
     const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
     if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");
-    {   // room for the largest group the grouping policy can form for this launch shape, so that a later, longer call does not reallocate
-        // (a reallocation waits for the stream: measured 0.3 ms inside a timed 20-pass call that followed a 5-pass warm-up)
-        const long long per_pass = (long long)g.n_busy * 64 * sub_samples;
-        const int kmax = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, INT32_MAX, max_bounce, carry);
-        int ks = 0; while ((1 << ks) < kmax) ks++;
-        if (ks < kshift) ks = kshift;
-        const size_t ws_bytes = rtw::group_workspace_bytes(((size_t)g.n_busy * 64 * (size_t)sub_samples) << ks, max_bounce, carry, nullptr);
-        rc = ensure_group_workspace(cx, ws_bytes); if (rc != RTW_OK) return rc;
-        if (cx->lane == 0 && cx->group_split && cx->stream2 && !use_base_color && kmax >= cx->split_min) {
-            // the second half's workspace now, not inside the first call that is long enough to be split (that call may be a timed one)
-            cx->lane = 1; rc = ensure_group_workspace(cx, ws_bytes); cx->lane = 0;
-            if (rc != RTW_OK) return rc;
-        }
-    }
+    // the workspace of THIS group (grow-only): a caller that must not stall inside a later, longer call reserves it with rtw_render_reserve
+    rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
     rtw::GroupTuning tune;
     tune.capacity = capacity;
     tune.aux_stream = cx->sky_split ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
@@ -1544,57 +1612,70 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
     rtw_context* cx = scene->ctx;
     if (group_pipeline_ok(scene)) {
         // groups of passes share one set of launches (rtw_group_kernels.h); the groups of this call fork the second stream once and join it once
-        if (task_rows < 1 || world < 1 || rank < 0 || rank >= world) return fail(RTW_ERR_INVALID, "bad task partition");
-        rc = check_render_args(scene, fb, max_bounce, first_pass, sub_samples); if (rc != RTW_OK) return rc;
-        RtwRenderParams p; std::memset(&p, 0, sizeof p);
-        const int n_tasks = (fb->height + task_rows - 1) / task_rows;
-        const int mine = n_tasks > rank ? (n_tasks - rank + world - 1) / world : 0;
-        p.begin = 0; p.task_rows = task_rows; p.rank = rank; p.world = world;
-        const int64_t cnt = world == 1 ? (int64_t)fb->width * fb->height : (int64_t)mine * task_rows * fb->width;
-        if (cnt > INT32_MAX) return fail(RTW_ERR_LIMIT, "too many work items");
-        p.count = (int)cnt;
-        if (p.count == 0) return RTW_OK;
-        // paths per pass: the busy tiles' pixels x sub-samples (known once the tile lists exist; the whole share until then)
-        long long per_pass = (long long)p.count * sub_samples;
-        {
-            RtwRenderParams t = p; t.width = fb->width; t.height = fb->height;
-            rtw_scene::BinSet* bs = nullptr; const rtw_scene::GroupTable* gt = nullptr;
-            if (!cx->stats_enabled && choose_group_tiles(t, 0, fb->width * fb->height - 1) && scene_bins(scene, t.width, t.height, t.tile_w, t.tile_h, &bs) == RTW_OK &&
-                scene_group_table(scene, *bs, t, sub_samples, &gt) == RTW_OK && gt) per_pass = (long long)gt->n_busy * 64 * sub_samples;
-        }
+        GroupCall gc;
+        rc = plan_group_call(scene, fb, task_rows, rank, world, max_bounce, first_pass, sub_samples, &gc); if (rc != RTW_OK) return rc;
+        if (gc.p.count == 0) return RTW_OK;
+        const RtwRenderParams& p = gc.p;
+        const long long per_pass = gc.per_pass;
+        const int last_pixel = fb->width * fb->height - 1;
+        cx->group_cap = 0;
         int done = 0;
         while (done < n_passes) {
-            const int k = use_base_color ? 1 : group_passes(cx, per_pass > 0 ? per_pass : 1, n_passes - done, max_bounce, scene->texture_carry);
+            bool split = false;
+            const int k = next_group(cx, per_pass, n_passes - done, max_bounce, scene->texture_carry, use_base_color != 0, &split);
             const bool first = done == 0, last = done + k >= n_passes;
             cx->batch_pos = (first && last) ? 0 : (first ? 1 : (last ? 3 : 2));
-            if (cx->group_split && k >= cx->split_min && per_pass * (k / 2) >= cx->split_paths && !use_base_color && !cx->stats_enabled && !cx->kernel_timing && cx->stream2) {
+            if (split) {
                 // The group as two halves on two streams.  Its kernels are bound by latency, not by a throughput roof: one half's short
                 // rounds and launch tails overlap the other's long ones.  Order kept: the sky kernel (second stream) takes all k passes of its pixels in a
                 // row; the second half's resolve kernel waits for the first half's, so a busy tile's passes are added in pass order.
                 const int ka = k / 2, kb = k - ka;
-                (void)hipEventRecord(cx->split_fork, cx->stream);
-                (void)hipStreamWaitEvent(cx->stream2, cx->split_fork, 0);
-                cx->lane = 0; cx->lane_sky_passes = k;
-                rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done, ka, sub_samples, seed);
-                (void)hipEventRecord(cx->split_mid, cx->stream);
-                if (rc == RTW_OK) {
-                    cx->lane = 1;
-                    rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done + ka, kb, sub_samples, seed);
+                // both halves' workspaces before anything of the group is launched: a refusal then leaves nothing half done
+                {
+                    RtwRenderParams t = p; t.width = fb->width; t.height = fb->height;
+                    size_t need = 0;
+                    if (choose_group_tiles(t, 0, last_pixel)) {
+                        int ks = 0; while ((1 << ks) < kb) ks++;
+                        need = rtw::group_workspace_bytes((size_t)per_pass << ks, max_bounce, scene->texture_carry, nullptr);
+                    }
+                    cx->lane = 0; rc = ensure_group_workspace(cx, need);
+                    if (rc == RTW_OK) { cx->lane = 1; rc = ensure_group_workspace(cx, need); }
+                    cx->lane = 0;
                 }
-                cx->lane = 0; cx->lane_sky_passes = 0;
-                (void)hipEventRecord(cx->split_join, cx->stream2);
-                (void)hipStreamWaitEvent(cx->stream, cx->split_join, 0);
+                if (rc == RTW_OK) {
+                    (void)hipEventRecord(cx->split_fork, cx->stream);
+                    (void)hipStreamWaitEvent(cx->stream2, cx->split_fork, 0);
+                    cx->lane = 0; cx->lane_sky_passes = k;
+                    rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, ka, sub_samples, seed);
+                    (void)hipEventRecord(cx->split_mid, cx->stream);
+                    if (rc == RTW_OK) {
+                        cx->lane = 1;
+                        rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done + ka, kb, sub_samples, seed);
+                    }
+                    cx->lane = 0; cx->lane_sky_passes = 0;
+                    (void)hipEventRecord(cx->split_join, cx->stream2);
+                    (void)hipStreamWaitEvent(cx->stream, cx->split_join, 0);
+                }
             } else
-                rc = render_group(scene, fb, p, false, 0, fb->width * fb->height - 1, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);
+                rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);
             cx->batch_pos = 0;
+            if (rc != RTW_OK && cx->ws_refused && k > 1) {
+                // no room for this group's workspace (the context's limit, or the device is full): nothing of the group has been launched -- form smaller
+                // groups for the rest of the call instead of failing (k = 1 needs ~300-600 bytes per path of one pass)
+                cx->ws_refused = false;
+                cx->group_cap = split ? (k + 1) / 2 : k / 2;
+                cx->fallbacks++;
+                continue;
+            }
             if (cx->aux_unjoined && (rc != RTW_OK || last)) {     // the run ends here (an error, or a last group that launched no sky kernel)
                 (void)hipEventRecord(cx->join_event, cx->aux_stream);
                 (void)hipStreamWaitEvent(cx->stream, cx->join_event, 0);
                 cx->aux_unjoined = false;
             }
-            if (rc != RTW_OK) return rc;
+            if (rc != RTW_OK) { cx->group_cap = 0; return rc; }
             done += k;
         }
+        cx->group_cap = 0;
         return RTW_OK;
     }
     rtw_context::PassGraph& g = cx->pass_graph;
@@ -1657,6 +1738,68 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
     }
     return RTW_OK;
 }
+
+// Everything a later rtw_render_passes call with these arguments needs that would otherwise be made inside it: the screen bins and tile tables of this
+// frame shape and the group workspace(s) of the largest group that call will form.  Renders nothing.
+int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world, int max_bounce, int n_passes, int sub_samples)
+{
+    int rc = need_committed(scene); if (rc != RTW_OK) return rc;
+    if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
+    if (n_passes < 0) return fail(RTW_ERR_INVALID, "bad pass count");
+    rtw_context* cx = scene->ctx;
+    if (!group_pipeline_ok(scene) || n_passes == 0) return RTW_OK;      // the older pipelines size their workspace by the frame, on first use
+    GroupCall gc;
+    rc = plan_group_call(scene, fb, task_rows, rank, world, max_bounce, 0, sub_samples, &gc); if (rc != RTW_OK) return rc;
+    if (gc.p.count == 0) return RTW_OK;
+    RtwRenderParams t = gc.p; t.width = fb->width; t.height = fb->height;
+    if (!choose_group_tiles(t, 0, fb->width * fb->height - 1)) return fail(RTW_ERR_LIMIT, "frame too large for the tile mapping");
+    size_t need0 = 0, need1 = 0;
+    const int saved_cap = cx->group_cap;
+    cx->group_cap = 0;
+    for (int done = 0; done < n_passes;) {
+        bool split = false;
+        const int k = next_group(cx, gc.per_pass, n_passes - done, max_bounce, scene->texture_carry, false, &split);
+        const int kk = split ? k - k / 2 : k;
+        int ks = 0; while ((1 << ks) < kk) ks++;
+        const size_t b = rtw::group_workspace_bytes((size_t)gc.per_pass << ks, max_bounce, scene->texture_carry, nullptr);
+        if (b > need0) need0 = b;
+        if (split && b > need1) need1 = b;
+        done += k;
+    }
+    cx->group_cap = saved_cap;
+    cx->lane = 0; rc = ensure_group_workspace(cx, need0);
+    if (rc == RTW_OK && need1 > 0) { cx->lane = 1; rc = ensure_group_workspace(cx, need1); cx->lane = 0; }
+    if (rc != RTW_OK && cx->ws_refused) { cx->ws_refused = false; return RTW_OK; }      // not an error: the call will form smaller groups
+    return rc;
+}
+
+// device memory this context holds right now: the group workspaces, the older pipelines' workspace and its share of the unit-vector table
+// (201 MB per device, shared by the contexts on it); scenes and framebuffers are the caller's objects and not counted
+long long rtw_context_memory_bytes(const rtw_context* ctx)
+{
+    if (!ctx) return 0;
+    return (long long)(ctx->group_ws_bytes + ctx->group_ws2_bytes + ctx->workspace_bytes + (size_t)RTW_TABLE_SIZE * 3 * sizeof(float) + 2 * 1024 + 64);
+}
+// ... of which workspace (grows with the largest group rendered so far; rtw_context_trim gives it back)
+long long rtw_context_workspace_bytes(const rtw_context* ctx)
+{
+    if (!ctx) return 0;
+    return (long long)(ctx->group_ws_bytes + ctx->group_ws2_bytes + ctx->workspace_bytes);
+}
+int rtw_context_trim(rtw_context* ctx)
+{
+    if (!ctx) return fail(RTW_ERR_INVALID, "context is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+    if (ctx->stream2) HIP_TRY(hipStreamSynchronize(ctx->stream2));
+    if (ctx->d_group_ws) { (void)hipFree(ctx->d_group_ws); ctx->d_group_ws = nullptr; ctx->group_ws_bytes = 0; ctx->group_clean = false; }
+    if (ctx->d_group_ws2) { (void)hipFree(ctx->d_group_ws2); ctx->d_group_ws2 = nullptr; ctx->group_ws2_bytes = 0; ctx->group_clean2 = false; }
+    if (ctx->d_workspace) { (void)hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_bytes = 0; ctx->clean_ws = nullptr; }
+    ctx->pass_graph.valid = false;
+    return RTW_OK;
+}
+int rtw_context_fallbacks(const rtw_context* ctx) { return ctx ? ctx->fallbacks : 0; }
 
 // ---- multi-GPU gather over RCCL -------------------------------------------------------------------------------------------------
 }  // extern "C"

@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"wave_below": 80000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0, "split_min": 8, "split_paths": 400000}
+DEFAULTS = {"workspace_limit_mb": 0, "wave_below": 80000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0, "split_min": 8, "split_paths": 400000}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 
@@ -130,6 +130,32 @@ def case_split(ctx):
     o = [("device_build", 0), ("split_min", 2), ("split_paths", 0)]
     frame_case(ctx, "two halves: mirror", mesh("TorusKnot", SC.reflective()), 96, 54, 1, 4, 7, options=o)
     frame_case(ctx, "two halves: SetupScene", SC.SCENES["default"](), 48, 48, 1, 4, 4, options=o, f64=True)
+
+
+def case_workspace(ctx):
+    """the workspace follows the groups a call forms; a refusal (here: the context's limit; on a GPU also a failing hipMalloc) re-forms smaller groups"""
+    m = mesh("TorusKnot", SC.reflective())
+    ctx.trim()
+    assert ctx.workspace_bytes() == 0
+    frame_case(ctx, "one pass per call", m, 96, 54, 1, 4, 1, options=[("device_build", 0)])
+    one = ctx.workspace_bytes()
+    frame_case(ctx, "7 passes, whole", m, 96, 54, 1, 4, 7, options=[("device_build", 0), ("split_min", 64)])
+    whole = ctx.workspace_bytes()
+    assert 0 < one and 4 * one <= whole <= 9 * one, (one, whole)          # 7 passes -> 8 slots per path
+    ctx.trim()
+    before = ctx.fallbacks()
+    frame_case(ctx, "7 passes under a 1 MB limit", m, 96, 54, 1, 4, 7, options=[("device_build", 0), ("workspace_limit_mb", 1), ("split_min", 64)])
+    assert ctx.fallbacks() > before and ctx.workspace_bytes() <= 1 << 20, (ctx.fallbacks(), before, ctx.workspace_bytes())
+    # a reserve ahead of the call: the call itself then allocates nothing
+    ctx.trim()
+    s = product_scene(ctx, m)
+    fb = R.Framebuffer(ctx, 96, 54)
+    s.render_reserve(fb, 10, 0, 1, 4, 7, 1)
+    reserved = ctx.workspace_bytes()
+    s.render_passes(fb, 10, 0, 1, 4, None, 0, 7, 1, 12345)
+    assert reserved > 0 and ctx.workspace_bytes() == reserved, (reserved, ctx.workspace_bytes())
+    fb.close(); s.close()
+    print("  workspace: one pass %d B, 7 passes %d B, reserved %d B" % (one, whole, reserved), flush=True)
 
 
 def case_device_build(ctx):

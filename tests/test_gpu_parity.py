@@ -961,3 +961,66 @@ def test_bench_multirank_code_path_rehearsed_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and "rehearsal" in d
     assert d["gather_verified_bit_identical_to_1gpu"] is True
     assert d["gather"].startswith("rtw_gather_rows")
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_no_launcher_did(tmp_path):
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset -- the way the driver issues its N = 1 command -- must start the two rank processes itself (before it
+    touches a GPU), relay rank 0's line and exit with their status.  Rehearsed on this one-GPU box (--rehearse: every rank on GPU 0, gloo, loopback transport
+    under rtw_gather_rows).  The line carries the C2 strong-scaling figures AND a `c5` block (BASELINE configs[4]) with its gather timed separately; both
+    gathered images verified against the one-GPU replay."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--rehearse"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and "rehearsal" in d
+    assert d["gather_verified_bit_identical_to_1gpu"] is True and d["gather"].startswith("rtw_gather_rows")
+    assert d["gather_ms"] is not None and d["gather_ms"] >= 0
+    c5 = d["c5"]
+    assert "3840x2160" in c5["workload"] and c5["steps"] == 4 and c5["gather_verified_bit_identical_to_1gpu"] is True
+    assert c5["gather_ms"] is not None and c5["ms_per_step"] > 0 and c5["value"] > 0
+
+
+@pytest.mark.gpu
+def test_workspace_follows_the_call_and_a_refusal_renders_in_smaller_groups(ctx):
+    """The group workspace is sized for the groups a call actually forms (round 2 sized it for the largest group the policy could ever form, twice:
+    10.6 GB to render a 1 200-triangle mesh).  C2's frame: one pass per call (rtw_render_range, the facade's default) stays under 200 MB of workspace, a
+    20-pass call under 1.5 GB of device memory in all (unit-vector table included); rtw_render_reserve ahead of a call leaves the call nothing to allocate;
+    and when a group's workspace is refused -- here by the context's limit, on a full device by hipMalloc -- the call renders the SAME image in smaller
+    groups (rtw_context_fallbacks counts) instead of failing."""
+    W, H, depth = 1920, 1080, 4
+    c2 = R.Context(0)
+    try:
+        s = gpu_scene(c2, "TorusKnot", R.SurfaceMaterial_Diffuse())
+        fb = R.Framebuffer(c2, W, H)
+        assert c2.workspace_bytes() == 0
+        R.ThreadWorker_Render(s, fb, 0, W * H - 1, depth, None, 0, 1, 12345)
+        c2.synchronize()
+        one = c2.workspace_bytes()
+        assert 0 < one <= 200 << 20, one
+        fb.clear()
+        s.render_reserve(fb, 10, 0, 1, depth, 20, 1)
+        reserved = c2.workspace_bytes()
+        s.render_passes(fb, 10, 0, 1, depth, None, 0, 20, 1, 12345)
+        c2.synchronize()
+        assert c2.workspace_bytes() == reserved and c2.fallbacks() == 0
+        assert c2.memory_bytes() <= 1500 << 20, c2.memory_bytes()
+        want = (fb.read_float(), fb.resolve_argb())
+        c2.trim()
+        assert c2.workspace_bytes() == 0
+        c2.set_option("workspace_limit_mb", 64)
+        fb.clear()
+        s.render_passes(fb, 10, 0, 1, depth, None, 0, 20, 1, 12345)
+        c2.synchronize()
+        got = (fb.read_float(), fb.resolve_argb())
+        assert c2.fallbacks() > 0 and c2.workspace_bytes() <= 2 * (64 << 20), (c2.fallbacks(), c2.workspace_bytes())
+        assert (bits(got[0]) == bits(want[0])).all() and (got[1] == want[1]).all()
+        assert c2.last_pass_pipeline() == 4
+        c2.set_option("workspace_limit_mb", 0)
+    finally:
+        c2.close()
