@@ -450,6 +450,8 @@ def measure(B, cfg, K, Wm, primary):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / K * 1e3
+    group_passes = ctx.last_group_passes()          # passes the timed call's last group held (both halves of a split group together)
+    memory_bytes = ctx.memory_bytes()               # workspaces of the timed call + the unit-vector table, before the untimed replays below grow anything
 
     res = None
     if rank == 0:
@@ -485,7 +487,7 @@ def measure(B, cfg, K, Wm, primary):
                "gather_ms": gather_ms, "rays_per_frame": rays_total / K, "camera_Mrays_per_s": cam_total / elapsed / 1e6,
                "verified": verified, "data": data, "depth": depth, "W": W, "H": H, "spp": spp, "kind": kind, "mesh_path": mesh_path,
                "commit_ms": commit_ms, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "pipeline_run": ctx.last_pass_pipeline(),
-               "memory_bytes": ctx.memory_bytes() if hasattr(ctx, "memory_bytes") else None}
+               "memory_bytes": memory_bytes, "group_passes": group_passes}
         if primary:
             st_run_pass = {k: v / K for k, v in st.items()}
             # reference-faithful visit counts (un-pruned DFS order: what KdNode::TestRayIntersection visits) of ONE pass
@@ -603,8 +605,7 @@ def main():
         # bytes per pass: SURVEY.md 8(d)'s weights on (a) the visits the reference's un-pruned walk makes, (b) the tests the timed kernels execute.
         # The framebuffer term as EXECUTED: a group of passes reads and writes a pixel's accumulator once and stores its ARGB word once (the per-pass
         # accumulate / divide / gamma arithmetic stays in registers), so 36 B per pixel and GROUP, i.e. 36 / passes-per-group per pixel-pass
-        group = max(1, B.ctx.last_group_passes()) if args.pipeline == 4 else 1
-        group = min(group, K)
+        group = min(max(1, m["group_passes"]), K) if args.pipeline == 4 else 1
         alg_ref = algorithmic_bytes(m["st_ref"], npix)
         alg_run = algorithmic_bytes(m["st_run_pass"], npix / float(group))
         tr, tr_src = profile_field("r03_traffic_%s.json" % args.config, sha) if world == 1 else (None, "N > 1: no per-rank profile")

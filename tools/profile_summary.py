@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """tools/profile_summary.py RAW_DIR TAG CONFIG -- condense the rocprofv3 output of tools/profile_round.sh into the files committed under
-profiles/: r02_<tag>_kernel_stats.csv (rocprofv3's own --stats table), r02_<tag>_bench.json (the bench line of the traced run),
-r02_traffic_<config>.json (HBM bytes per pass from FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) and
-r02_<tag>_insts.json (VALU / SALU instructions per kernel and per secondary ray)."""
+profiles/: RND_<tag>_kernel_stats.csv (rocprofv3's own --stats table), RND_<tag>_bench.json (the bench line of the traced run),
+RND_traffic_<config>.json (HBM bytes per pass from FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) and
+RND_<tag>_insts.json (VALU / SALU instructions per kernel and per secondary ray).  RND = $RTW_ROUND (default r03).  Every file records the hash of the
+kernels it was taken on (`kernels_sha`, from the traced run's rtw_version()): bench.py prints a figure from here only when that hash is the loaded library's."""
 import csv
 import glob
 import json
@@ -12,6 +13,7 @@ import shutil
 import sys
 
 raw, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
+RND = os.environ.get("RTW_ROUND", "r03")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
@@ -61,11 +63,20 @@ out = {}
 bl = bench_line("kt")
 steps = bl["steps"] if bl else 20
 warm = bl["warmup"] if bl else 5
+
+
+def sha_of(line):
+    v = (line or {}).get("library", "")
+    return v.split("kernels ")[1].split(")")[0].strip() if "kernels " in v else None
+
+
+KSHA = sha_of(bl)
+out["kernels_sha"] = KSHA
 if bl:
-    json.dump(bl, open(os.path.join(PROF, "r02_%s_bench.json" % tag), "w"), indent=1)
+    json.dump(bl, open(os.path.join(PROF, "%s_%s_bench.json" % (RND, tag)), "w"), indent=1)
 st = find("kt", "*kernel_stats.csv")
 if st:
-    shutil.copy(st, os.path.join(PROF, "r02_%s_kernel_stats.csv" % tag))
+    shutil.copy(st, os.path.join(PROF, "%s_%s_kernel_stats.csv" % (RND, tag)))
 # per-kernel durations inside the timed call
 kt = find("kt", "*kernel_trace.csv")
 if kt:
@@ -109,13 +120,13 @@ if fe and wr:
         wb = wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
         per_kernel[k] = {"hbm_read_bytes_per_pass": rd / steps, "hbm_write_bytes_per_pass": wb / steps, "fetch_doubled": k in STREAMING}
         total += (rd + wb) / steps
-    traffic = {"workload": bl["config"]["workload"] if bl else cfg, "steps_in_the_timed_call": steps, "hbm_bytes_per_pass": total, "per_kernel": per_kernel,
+    traffic = {"kernels_sha": sha_of(bench_line("fetch")) or KSHA, "workload": bl["config"]["workload"] if bl else cfg, "steps_in_the_timed_call": steps, "hbm_bytes_per_pass": total, "per_kernel": per_kernel,
                "ms_per_step_of_the_traced_run": bl["ms_per_step"] if bl else None,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --config %s --no-cpu --steps %d --warmup %d` (tools/profile_round.sh); "
                          "KB * 1024 summed over the dispatches of the timed rtw_render_passes call, divided by its passes; FETCH doubled for the kernels that stream 16 B per lane "
                          "(gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md 'HBM'); gather-style kernels left uncorrected (uncalibrated width); Infinity-Cache hits are "
                          "counted by these counters, so this is an upper bound of what reaches HBM" % (cfg, steps, warm)}
-    json.dump(traffic, open(os.path.join(PROF, "r02_traffic_%s.json" % cfg), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(PROF, "%s_traffic_%s.json" % (RND, cfg)), "w"), indent=1)
     out["hbm_bytes_per_pass"] = total
 if ins:
     il = bench_line("insts") or bl
@@ -126,14 +137,14 @@ if ins:
     tr = {k: v for k, v in ins.items() if k.startswith("gtrace") or k.startswith("trace_wave")}
     valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in tr.values())
     salu = sum(v.get("SQ_INSTS_SALU", 0.0) for v in tr.values())
-    res = {"per_kernel_in_the_timed_call": ins, "steps_in_the_timed_call": steps, "secondary_rays_in_the_timed_call": sec,
+    res = {"kernels_sha": sha_of(il) or KSHA, "per_kernel_in_the_timed_call": ins, "steps_in_the_timed_call": steps, "secondary_rays_in_the_timed_call": sec,
            "valu_instructions_per_pass": sum(v.get("SQ_INSTS_VALU", 0.0) for v in ins.values()) / steps,
            "trace_kernels_valu_instructions_per_secondary_ray": valu / sec if sec else None,
            "trace_kernels_salu_instructions_per_secondary_ray": salu / sec if sec else None,
            "note": "SQ_INSTS_VALU / SQ_INSTS_SALU are per-wave instruction counts summed over the dispatch; divided by the secondary rays the timed call traced (bench counters)"}
-    json.dump(res, open(os.path.join(PROF, "r02_%s_insts.json" % tag), "w"), indent=1)
+    json.dump(res, open(os.path.join(PROF, "%s_%s_insts.json" % (RND, tag)), "w"), indent=1)
     out["valu_per_secondary_ray"] = res["trace_kernels_valu_instructions_per_secondary_ray"]
-json.dump(out, open(os.path.join(PROF, "r02_%s_timeline.json" % tag), "w"), indent=1)
+json.dump(out, open(os.path.join(PROF, "%s_%s_timeline.json" % (RND, tag)), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "timed_call"}))
 if "timed_call" in out:
     print("span per step %.1f us" % out["timed_call"]["span_us_per_step"])
