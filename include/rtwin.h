@@ -80,42 +80,27 @@ int rtw_context_destroy(rtw_context* ctx);
 /* run every later launch of this context on the caller's hipStream_t (e.g. torch's) */
 int rtw_context_set_stream(rtw_context* ctx, void* hip_stream);
 int rtw_context_synchronize(rtw_context* ctx);
-/* Tuning switches; results never depend on them (every combination is tested bit-identical).
+/* Switches; results never depend on them (every combination is tested bit-identical).
  *   "pipeline"      4 (default) = pass-batched: the passes of one rtw_render_passes call are rendered in groups that share one set of launches (screen
  *                   bins for the camera rays, a ray per lane for the bounce rounds; rtw_group_kernels.h), every frame shape, pixel range and scene;
- *                   3 = screen bins for the camera rays (hits shaded in the same kernel, sky tiles in a
- *                   second kernel on a side stream) + one wave-per-ray trace launch and one shade launch per bounce;
- *                   2 = packet walk for camera rays + a 16-lanes-per-ray trace and a shade launch per bounce;
- *                   1 = packet walk + one path kernel + resolve; 0 = one kernel, one thread per pixel.
- *   pipeline 3:     "direct_slots" (1) camera-ray hits are shaded by the primary kernel; "batch_passes" (1) the passes of one rtw_render_passes call fork the second stream once and join it once;
- *                   "auto_fused" (1) below about 10 k queued paths per pass (a rank's share of a small frame) the one-kernel-
- *                   for-all-bounces variant is used; "finish_in_trace" (0) when no material emits, the last trace round ends its paths itself (no last shade launch; slower);
- *                   "resolve_inline" (1) with one sample per pixel the lane that ends a path resolves its pixel (no resolve
- *                   launch); "lead_split" (1) the scene's leading spheres / planes / capsules are tested by
- *                   the lane that sets a segment up, the trace waves continue from its record; "sky_split" (1) sky-only tiles
- *                   in their own kernel; "wave_stage" (0) LDS staging of shape 0 in the trace kernels, 1..3 = levels /
- *                   leaves / triangles, -1 = as much as fits; "wave_fused" (0) one kernel carries the paths through all
- *                   bounces; "wave_tail" (0) one kernel after the first trace round; "wave_paths", "wave_blocks_mul",
- *                   "primary_blocks_per_cu": launch geometry; "use_graph" (0) rtw_render_passes replays a launch graph;
- *                   "hint_period" (16) the queue lengths that size the next launches are read back every n-th pass.
- *   pipelines 1, 2: "packets" (1) camera rays traced as 64-ray packets inside the primary kernel; "path_lanes" lanes per
- *                   ray in the path kernel: 16 (default), 4 or 1; "path_variant": occupancy variants of the path kernel.
- *   "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms).
- *   Pass-batched pipeline (4): "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold;
- *                   "group_split" (1) a group of at least "split_min" (8) passes and 2 x "split_paths" (400 000) paths runs as two halves on two streams
- *                   (second workspace of the same size);
- *                   "trace_stage" (1) the trace blocks stage the first mesh's upper tree levels in LDS; "trace_persist" (1) one-mesh scenes: persistent
- *                   trace waves that refill their lanes; "wave_below" (80 000; x 5 for trees of more than 4 096 nodes) a trace round with fewer rays runs a wave per ray; "wide_below" (0)
- *                   sixteen lanes per ray between wave_below and this (measured slower); "visit_budget" (384) one-mesh scenes: a ray's node visits in the
- *                   ray-per-lane kernel before it goes to the wave-per-ray one (a rare ray that walks a thousand nodes kept its whole wave waiting: the
- *                   slowest C2 call in 24 went from 1.17 to 0.98 ms), for trees with more than "budget_nodes" (0) nodes; "device_build" (1) tree, layouts and screen bins built on the device. */
+ *                   3 = one pass per set of launches: screen bins for the camera rays + one wave-per-ray trace launch and one shade launch per bounce
+ *                   (the one-pass reference the pass-batched pipeline is compared with); 0 = one kernel, one thread per pixel (with
+ *                   rtw_scene_set_traversal(0): the reference's own visit order, for the work counters).
+ *   "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold; "group_split" (1) a group of at least
+ *                   "split_min" (8) passes and 2 x "split_paths" (400 000) paths runs as two halves on two streams (a second workspace of the same size);
+ *   "wave_below" (80 000; x 5 for trees of more than 4 096 nodes) a trace round with fewer rays runs a wave per ray; "visit_budget" (384) one-mesh scenes:
+ *                   a ray's node visits in the ray-per-lane kernel before it goes to the wave-per-ray one (a rare ray that walks a thousand nodes kept its
+ *                   whole wave waiting), for trees with more than "budget_nodes" (0) nodes;
+ *   "workspace_limit_mb" (0 = 24 GiB) a group's workspace may not exceed this: larger groups are re-formed smaller (see rtw_context_memory_bytes);
+ *   "device_build" (1) tree, layouts and screen bins built on the device; "hint_period" (16) pipeline 3: the queue lengths that size the next launches
+ *                   are read back every n-th pass; "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms). */
 int rtw_context_set_option(rtw_context* ctx, const char* name, int value);
 /* with option "kernel_timing" = 1: HIP-event durations (ms) of the latest pass's three stages -- primary kernel(s),
  * the per-bounce trace / shade launches, resolve -- measured on the context's stream; waits for that pass. */
 int rtw_last_pass_kernel_ms(rtw_context* ctx, float out3[3]);
 /* passes the latest group of the pass-batched pipeline held (rtw_last_pass_kernel_ms times that group) */
 int rtw_last_group_passes(rtw_context* ctx);
-/* the pipeline the latest render call of this context actually ran (0..4; -1 before the first call): lets a caller see a fallback */
+/* the pipeline the latest render call of this context actually ran (0, 3 or 4; -1 before the first call): lets a caller see a fallback */
 int rtw_last_pass_pipeline(rtw_context* ctx);
 const char* rtw_last_error(void);
 const char* rtw_version(void);
@@ -130,8 +115,7 @@ int rtw_scene_add_mesh_obj(rtw_scene* scene, const char* obj_path, int* out_shap
  * radius) (Src/Shapes.h:46-112; intersections Src/RRay.cpp:25-87 and Src/Shapes.cpp:18-125).  Shapes keep their insertion order
  * (it decides which of two hits at one distance wins, and which hit's sampled colour a later sphere / plane / capsule-side hit
  * inherits: one RayHitResult serves all shapes of a query, Src/RayTracerScene.cpp:99-125).  A plane has no culling box
- * (RPlane::HasCullingBounds).  The material is set with rtw_scene_set_material as for a mesh.  Scenes with such shapes render
- * through the bins + wave pipeline or, when a textured mesh precedes one of them, through the single kernel (pipeline 0). */
+ * (RPlane::HasCullingBounds).  The material is set with rtw_scene_set_material as for a mesh. */
 int rtw_scene_add_sphere(rtw_scene* scene, const float center[3], float radius, int* out_shape);
 int rtw_scene_add_plane(rtw_scene* scene, const float normal[3], const float point[3], int* out_shape);
 int rtw_scene_add_capsule(rtw_scene* scene, const float start[3], const float end[3], float radius, int* out_shape);
@@ -163,12 +147,10 @@ int rtw_scene_mesh_info(const rtw_scene* scene, int shape, int32_t info[8], floa
 int rtw_scene_mesh_nodes(const rtw_scene* scene, int shape, float* bounds6, int32_t* skip, int32_t* tri, int max_nodes);
 /* traversal pruning (result-preserving segment clip); default on */
 int rtw_scene_set_prune(rtw_scene* scene, int enabled);
-/* 1 (default): 4-wide collapsed tree, candidate leaves gathered in the reference's order before their
- * triangle tests; 0: binary preorder walk that visits exactly the boxes KdNode::TestRayIntersection
- * visits (Src/KdTree.cpp:128-195; used for reference-faithful work counters).  Same results. */
+/* 1 (default): screen bins, link tree and flat hierarchy may be used (candidate leaves gathered in the reference's order before their
+ * triangle tests); 0: every ray walks the binary tree in preorder, visiting exactly the boxes KdNode::TestRayIntersection
+ * visits (Src/KdTree.cpp:128-195; one thread per pixel; used for reference-faithful work counters).  Same results. */
 int rtw_scene_set_traversal(rtw_scene* scene, int mode);
-/* 4-wide tree for inspection: returns the quad count; child4 as in rtw_types.h (leaf = -1 - original triangle) */
-int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int32_t* child4, int max_quads);
 /* The flat hierarchy over the leaves in preorder that the wave-per-ray walk uses: level 0 = each
  * leaf's own box (KdNode::Bounds of the leaf, Src/KdTree.cpp:37-60), level 1 / 2 = unions of 16 /
  * 256 consecutive leaves.  boxes6 = min.xyz, max.xyz per entry.  Returns the level's entry count. */
@@ -222,9 +204,9 @@ int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int r
                      int max_bounce, int use_base_color, int pass_index, int sub_samples, uint32_t seed);
 /* UpdateBitmapPixels' sample loop (Src/RayTracerProgram.cpp:317-361): n_passes accumulated passes
  * first_pass .. first_pass + n_passes - 1 over this rank's tasks, as rtw_render_tasks would render
- * them one by one (same images).  With the context option "use_graph" the library captures one pass
- * as a launch graph (pass index on the device) and replays it per pass; measured on MI355X the passes
- * are GPU-bound, so the default launches every pass kernel by kernel. */
+ * them one by one (same final images).  The passes are rendered in groups that share one set of launches; a pixel's per-pass colour,
+ * accumulate, divide and gamma run once per pass in pass order, its accumulator entry and ARGB word are written once per group:
+ * intermediate images are not materialised inside a call (call it with n_passes = 1 to show every pass). */
 int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
                       int max_bounce, int use_base_color, int first_pass, int n_passes,
                       int sub_samples, uint32_t seed);

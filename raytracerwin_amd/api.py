@@ -491,15 +491,6 @@ class RayTracerScene:
         _check(library().rtw_scene_mesh_nodes(self.h, shape, _p(b), _p(s), _p(t), n))
         return b, s, t
 
-    def mesh_quads(self, shape=0):
-        self.commit()
-        n = library().rtw_scene_mesh_quads(self.h, shape, None, None, 0)
-        _check(n)
-        b = np.zeros((n, 6, 4), np.float32)
-        c = np.zeros((n, 4), np.int32)
-        _check(library().rtw_scene_mesh_quads(self.h, shape, _p(b), _p(c), n))
-        return b, c
-
     def mesh_flat(self, level, shape=0):
         """boxes (n, 6) of one level of the flat leaf hierarchy (0 = leaves in preorder, 1 = groups of 16, 2 = groups of 256)"""
         self.commit()

@@ -16,24 +16,13 @@ inline size_t level_workspace_bytes(long long work_items, int max_bounce)
     const size_t threads = (size_t)((work_items + 255) / 256) * 256;
     return threads * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
 }
-struct PipelineLayout {
-    size_t queue_off, pend_off, counters_off, rad_off, hit_off, ws_off, total; int path_quartets;
-    size_t wf_capacity, wf_state_off, wf_tlist0_off, wf_tlist1_off, wf_ws_off, wf_total;
-};
-#define RTW_MAX_PATH_QUARTETS (1 << 20)   // quartets (paths in flight) of one path_kernel launch; more paths loop
-#define RTW_PATH_BLOCK_LDS 512            // threads per block when the quads are staged in LDS
-// workspace of the compacted pipeline for a launch of `work_items` pixels (device bytes)
-size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out);   // out->wf_total when the wavefront pipeline is used
-// lds_quad_count: how many of shape 0's quads (breadth-first order) each path_kernel block stages in LDS
+struct PipelineLayout { size_t queue_off, pend_off, counters_off, rad_off, hit_off, state_off, tlist0_off, tlist1_off, ws_off, total, capacity; };
+// workspace of the bins + wave pipeline (pipeline 3) for a launch of `work_items` pixels (device bytes)
+size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out);
 struct PipelineTuning {
-    int path_lanes;        // lanes per ray in the path kernel: 16, 4 or 1
-    int lds_wide_count;    // path_lanes 16: 16-wide nodes of shape 0 staged in LDS (0 = read through L2)
-    int path_variant;      // path_lanes 16: 0 = default geometry, 1..3 = occupancy experiments (see launch_render_pipeline)
     int expected_paths;    // queue length seen by the previous pass on this context, -1 = unknown
-    int round_hint[32];    // wavefront: trace-list lengths of the previous pass per round, -1 = unknown
-    int wave_stage;        // bins + wave pipeline: what pathwave_kernel's blocks stage in LDS for shape 0 (0 nothing .. 3 levels + triangles)
-    size_t wave_stage_bytes;   // bytes of those arrays
-    // bins + wave pipeline: jobs [sky_job0, n_jobs) of the job table are sky-only tiles, rendered by primary_sky_kernel on aux_stream
+    int round_hint[32];    // trace-list lengths of the previous pass per round, -1 = unknown
+    // jobs [sky_job0, n_jobs) of the job table are sky-only tiles, rendered by primary_sky_kernel on aux_stream
     // between the two events (fork after the previous work of the main stream, join before the pass ends); aux_stream null = one kernel
     hipStream_t aux_stream; hipEvent_t fork_event, join_event; int sky_job0; const float* gamma_thr;
     bool has_analytic = false;  // some shape is a sphere / plane / capsule: the kernels' instantiations that hold those tests are launched
@@ -42,18 +31,12 @@ struct PipelineTuning {
     // kernel of the run writes
     bool do_fork = true, do_join = true;
     bool* aux_unjoined = nullptr;   // set when a sky kernel was launched and the join was left to a later pass
-    bool finish_in_trace = false;   // the last trace round finishes its paths itself (see trace_wave_kernel FINISH): no last shade launch
     bool skip_trace = false;    // every shape is a leading analytic shape: the shading lanes do the whole scene query, no trace launches
     bool counters_clean;   // the counters are known to be zero (left so by the previous pass): no memset
-    int trace_block;       // threads per block of the unstaged trace kernel: 256 (default), 128 or 64
-    int wave_blocks_mul;   // unstaged trace rounds: at most wave_blocks * 4 * wave_blocks_mul blocks of 4 waves (a wave takes rays in turn)
-    int wave_tail;         // 1: after the first trace round one kernel finishes the frame (no launch per later bounce)
-    int wave_fused;        // 1: pathwave_kernel carries the paths to their end, 0: one shade + one wave-per-ray trace launch per bounce
-    int primary_blocks_per_cu;   // bins + wave pipeline: blocks per CU of the persistent primary kernel
-    int wave_blocks;       // staged variants: blocks to launch at most (one per CU)
-    hipEvent_t* timing;    // null, or 4 events recorded before the primary kernel and after each of the three kernels
+    int cu_count;
+    hipEvent_t* timing;    // null, or 4 events recorded before the primary kernel and after each of the three stages
 };
-int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream);
+int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, const PipelineTuning& tune, bool stats, hipStream_t stream);
 // device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)
 size_t pipeline_counters_offset(long long work_items, int max_bounce);
 // ---- pass-batched pipeline (pipeline 4, rtw_group_kernels.h) ----
@@ -70,7 +53,7 @@ struct GroupTuning {
     bool counters_clean = false;   // the list counters are zero (left so by the previous group)
     int round_hint[32];            // list lengths of the previous group per round (-1 = unknown): they size the launches
     int cu_count = 256;
-    bool single_mesh = false, persist = true; // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
+    bool single_mesh = false;      // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
     // a group rendered as two halves on two streams (rtwin_capi.cpp: render_passes): the first half's sky kernel takes the passes of both,
     // the second half launches none and its resolve kernel waits for the first half's
     int sky_passes = 0; bool no_sky = false; hipEvent_t resolve_after = nullptr;
@@ -78,7 +61,6 @@ struct GroupTuning {
     int trace_hint[32];                      // scenes with leading analytic shapes: how many rays of a round still went to the trace launch (previous group)
     bool skip_trace = false;                 // every shape is a leading analytic shape: the shading lanes do the whole query, no trace launches
     int overflow_hint[32];                   // how many rays that were in the previous group, per round (-1 = unknown)
-    int wide_below = 0; bool wide_ok = false;  // lists between wave_below and wide_below rays run sixteen lanes per ray on the 16-wide tree (all meshes have one)
     int wave_below = 0;                      // a trace round whose list (previous group's length) is shorter than this runs a wave per ray
     bool staged_all = false;                 // ... and that is the shape's whole tree
     int staged_shape = -1, staged_top = 0;   // the trace blocks stage the first staged_top tnodes records of this shape in LDS (-1: nothing staged)
@@ -98,8 +80,6 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
 int device_build_bins(const RtwNode* d_nodes, const RtwTri* d_tris, int n_nodes, int width, int height, int bin_w, int bin_h,
                       uint32_t** off_out, uint32_t** ent_out, uint32_t* h_off, int* has_bins, hipStream_t stream);
 #define RTW_TNODES_TOP_BUDGET 3072 // records (32 B each) of a tree's upper levels a block of the ray-per-lane trace kernel stages in LDS: 96 KiB
-#define RTW_LDS_WIDE_BUDGET 160   // 16-wide nodes (448 B each) that may be staged in LDS: 70 KiB -> two 256-thread blocks per CU
-#define RTW_LDS_QUAD_BUDGET 1024  // quads (128 B each) that may be staged in LDS beside the per-quartet trails and lists
 int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream);
 int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float* hits11, int* shape, int* tri, bool stats, hipStream_t stream);
 int launch_ray_trace(const RtwSceneDev* sc, const float* rays, const uint32_t* keys2, long long n, int max_bounce, int preview,

@@ -123,20 +123,6 @@ __device__ __forceinline__ uint32_t lldu(const uint32_t* p, int i) { return p[i]
 __device__ __forceinline__ void lstu(uint32_t* p, int i, uint32_t v) { p[i] = v; }
 #endif
 
-// RTW_BOUNDS_DEBUG build: every indexed global access is range-checked first; a violation is recorded in
-// stats[6] (site code) / stats[7] (offending value) and the access is skipped instead of faulting.
-#ifdef RTW_BOUNDS_DEBUG
-#define RTW_IN_RANGE(sc, code, v, n) rtw_in_range(sc, code, (long long)(v), (long long)(n))
-__device__ __forceinline__ bool rtw_in_range(const RtwSceneDev* sc, int code, long long v, long long n)
-{
-    if (v >= 0 && v < n) return true;
-    if (sc->stats) { atomicMax(&sc->stats[6], (unsigned long long)code); sc->stats[7] = (unsigned long long)v; }
-    return false;
-}
-#else
-#define RTW_IN_RANGE(sc, code, v, n) true
-#endif
-
 struct Ray { f3 o, d; float dist; };
 struct Hit { f3 pos, normal; float dist; f3 color; float alpha; };
 
@@ -226,7 +212,6 @@ __device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, co
     const float4* nd4 = reinterpret_cast<const float4*>(nodes);
     const float4* tr4 = reinterpret_cast<const float4*>(tris);
     while (i < n_nodes) {
-        if (!RTW_IN_RANGE(sc, 1, i, n_nodes)) break;
         const float4 lo = gld4(nd4, 2 * (size_t)i), hi = gld4(nd4, 2 * (size_t)i + 1);
         const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
         bool hit; float tmin, tmax;
@@ -242,7 +227,7 @@ __device__ __forceinline__ bool tree_walk(const RtwSceneDev* __restrict__ sc, co
             hit = slab_exact(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, tmin, tmax);
         }
         if (STATS) ct.boxes++;
-        if (hit && leaf >= 0 && RTW_IN_RANGE(sc, 2, leaf, n_tris)) {
+        if (hit && leaf >= 0) {
             const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
             if (STATS) ct.tris++;
             f3 cp; float dist;
@@ -313,373 +298,9 @@ __device__ __forceinline__ bool packet_walk(const RtwNode* nodes, const RtwTri* 
     return any;
 }
 
-// ---- 4-wide walk -------------------------------------------------------------------------------------
-// Per-lane working memory in LDS: a trail of (quad, remaining-slot mask) per tree level and the list of
-// candidate leaves gathered so far, both indexed [entry * block_threads + thread] (conflict-free).
-// `tid`/`nthr` index the owner of a list: a lane (one lane per ray) or a quartet (four lanes per ray).
-struct TravCtx {
-    uint32_t* trail;            // RTW_QUAD_STACK entries per owner
-    uint32_t* cand;             // RTW_CAND_CAP entries per owner
-    const float* lds_quads;     // all quads of shape 0, staged in LDS by the block (quartet kernels only; may be null)
-    int tid, nthr;
-    int lane4;                  // lane & 3 (quartet kernels)
-    bool count;                 // this lane adds the per-ray counters (lane 0 of a quartet, or every lane)
-};
-#define RTW_TRAV_LDS_WORDS ((RTW_QUAD_STACK + RTW_CAND_CAP) * 256)
-
-__device__ __forceinline__ TravCtx make_trav(uint32_t* lds_words)
-{
-    TravCtx t;
-    t.trail = lds_words; t.cand = lds_words + RTW_QUAD_STACK * 256;
-    t.lds_quads = nullptr;
-    t.tid = (int)threadIdx.x; t.nthr = 256; t.lane4 = 0; t.count = true;
-    return t;
-}
-// sixteen lanes per ray: owner = group of 16
-__device__ __forceinline__ TravCtx make_trav16(uint32_t* lds_words, int block_threads, const float* lds_wides)
-{
-    TravCtx t;
-    const int groups = block_threads / 16;
-    t.trail = lds_words; t.cand = lds_words + RTW_WIDE_STACK * groups;
-    t.lds_quads = lds_wides;
-    t.tid = (int)(threadIdx.x >> 4); t.nthr = groups; t.lane4 = (int)(threadIdx.x & 15u); t.count = (threadIdx.x & 15u) == 0u;
-    return t;
-}
-// four lanes per ray: owner = quartet
-__device__ __forceinline__ TravCtx make_trav4(uint32_t* lds_words, int block_threads, const float* lds_quads)
-{
-    TravCtx t;
-    const int quartets = block_threads / 4;
-    t.trail = lds_words; t.cand = lds_words + RTW_QUAD_STACK * quartets;
-    t.lds_quads = lds_quads;
-    t.tid = (int)(threadIdx.x >> 2); t.nthr = quartets; t.lane4 = (int)(threadIdx.x & 3u); t.count = (threadIdx.x & 3u) == 0u;
-    return t;
-}
-
-// Same result as tree_walk<true>: the leaves whose own box the ray's line hits are met in the binary tree's
-// preorder (slots are ordered, children are walked depth-first), gathered RTW_CAND_CAP at a time, and then
-// triangle-tested in that order with the shrinking segment, exactly as KdNode::TestRayIntersection does.
-// Box tests of a gathering phase use the segment length known when the phase started (still conservative).
-template <bool STATS>
-__device__ __forceinline__ bool quad_walk(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
-                                          float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
-{
-    const float ix = 1.0f / r.d.x, iy = 1.0f / r.d.y, iz = 1.0f / r.d.z;
-    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
-    const float4* gq = reinterpret_cast<const float4*>(sh.quads);
-    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
-    bool any = false;
-    int sp = 0;                 // trail depth
-    uint32_t m = 0;             // remaining hit slots of the current quad (bit k = slot k)
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    int q = 0;
-    bool need_node = true;      // the next step loads quad q and tests its four boxes
-    bool walking = true;
-    while (walking) {
-        int ncand = 0;
-        // ---- gather: walk until the candidate list is full or the tree is exhausted ----
-        for (;;) {
-            if (need_node) {
-                const size_t qb = (size_t)q * 8;
-                const float4 mnx = gld4(gq, qb), mny = gld4(gq, qb + 1), mnz = gld4(gq, qb + 2);
-                const float4 mxx = gld4(gq, qb + 3), mxy = gld4(gq, qb + 4), mxz = gld4(gq, qb + 5), chf = gld4(gq, qb + 6);
-                c0 = __float_as_int(chf.x); c1 = __float_as_int(chf.y); c2 = __float_as_int(chf.z); c3 = __float_as_int(chf.w);
-                const float far_t = cur_dist + (eps_t + 1.0e-4f * cur_dist);
-                m = 0;
-#define RTW_SLOT(K, MNX, MNY, MNZ, MXX, MXY, MXZ, CH)                                                        \
-                {                                                                                             \
-                    const float x1 = (MNX - r.o.x) * ix, x2 = (MXX - r.o.x) * ix;                             \
-                    const float y1 = (MNY - r.o.y) * iy, y2 = (MXY - r.o.y) * iy;                             \
-                    const float z1 = (MNZ - r.o.z) * iz, z2 = (MXZ - r.o.z) * iz;                             \
-                    const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));             \
-                    const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));             \
-                    bool h = (tmax > tmin) && (CH != RTW_QUAD_EMPTY);                                          \
-                    if (prune) h = h && !(tmin > far_t) && !(tmax < -eps_t);                                  \
-                    if (h) m |= 1u << K;                                                                      \
-                }
-                RTW_SLOT(0, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, c0)
-                RTW_SLOT(1, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, c1)
-                RTW_SLOT(2, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, c2)
-                RTW_SLOT(3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, c3)
-#undef RTW_SLOT
-                if (STATS) ct.boxes += (c0 != RTW_QUAD_EMPTY) + (c1 != RTW_QUAD_EMPTY) + (c2 != RTW_QUAD_EMPTY) + (c3 != RTW_QUAD_EMPTY);
-                need_node = false;
-            }
-            // consume slots in order: leaves join the list, the first internal slot is descended into
-            int next = -1;
-            bool full = false;
-            for (;;) {
-                if (m == 0u) {
-                    if (sp == 0) break;
-                    sp--;
-                    const uint32_t e = lldu(tc.trail, sp * tc.nthr + tc.tid);
-                    q = (int)(e >> 4); m = e & 15u;
-                    const float4 chf = gld4(gq, (size_t)q * 8 + 6);
-                    c0 = __float_as_int(chf.x); c1 = __float_as_int(chf.y); c2 = __float_as_int(chf.z); c3 = __float_as_int(chf.w);
-                    continue;
-                }
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1u;
-                const int ch = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-                if (ch < 0) {
-                    lstu(tc.cand, ncand * tc.nthr + tc.tid, (uint32_t)(-1 - ch));
-                    ncand++;
-                    if (ncand == RTW_CAND_CAP) { full = true; break; }
-                    continue;
-                }
-                next = ch;
-                break;
-            }
-            if (next >= 0) {
-                if (m != 0u) { lstu(tc.trail, sp * tc.nthr + tc.tid, ((uint32_t)q << 4) | m); sp++; }
-                q = next; need_node = true;
-                continue;
-            }
-            if (!full) walking = false;      // trail empty and no slot left: the tree is exhausted
-            break;
-        }
-        // ---- triangle tests of the gathered leaves, in order ----
-        for (int j = 0; j < ncand; j++) {
-            const int leaf = (int)tc.cand[j * tc.nthr + tc.tid];
-            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
-            if (STATS) ct.tris++;
-            f3 cp; float dist;
-            if (triangle_test(r, cur_dist, a, b, c, d.x, cp, dist)) { cur_dist = dist; hit_pos = cp; hit_slot = leaf; any = true; }
-        }
-    }
-    return any;
-}
-
-// ---- 4-wide walk, four lanes per ray -----------------------------------------------------------------
-// The four lanes of a quartet hold the same ray and the same control state; lane k owns slot k of the
-// current quad (one box test per lane instead of four), the hit mask is the quartet's nibble of the wave
-// ballot, and candidate leaves are triangle-tested four at a time.  A triangle test must see the segment
-// length left by every earlier accepted hit (the reference tests them one after another), so after an
-// accept the later lanes of the group are tested again with the shortened segment.
-__device__ __forceinline__ int quad_bcast(int v, int k)      // value of lane k of this lane's quartet
-{
-    const int b0 = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
-    const int b1 = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
-    const int b2 = __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true);
-    const int b3 = __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true);
-    return k == 0 ? b0 : (k == 1 ? b1 : (k == 2 ? b2 : b3));
-}
-__device__ __forceinline__ float quad_bcastf(float v, int k) { return __int_as_float(quad_bcast(__float_as_int(v), k)); }
-
-template <bool STATS, bool LDSQ>
-__device__ __forceinline__ bool quad_walk4(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
-                                           float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
-{
-    const float ix = 1.0f / r.d.x, iy = 1.0f / r.d.y, iz = 1.0f / r.d.z;
-    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
-    const float* gqf = reinterpret_cast<const float*>(sh.quads);
-    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
-    const int k4 = tc.lane4;
-    const int nibble_shift = (int)(threadIdx.x & 60u);       // first lane of this quartet within the wave
-    bool any = false;
-    int sp = 0;
-    uint32_t m = 0;
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    int q = 0;
-    bool need_node = true;
-    bool walking = true;
-    while (walking) {
-        int ncand = 0;
-        for (;;) {
-            if (need_node) {
-                float mnx, mny, mnz, mxx, mxy, mxz; int ch;
-                const int qb = q * 32 + k4;
-                if (LDSQ) {
-                    mnx = lld1(tc.lds_quads, qb); mny = lld1(tc.lds_quads, qb + 4); mnz = lld1(tc.lds_quads, qb + 8);
-                    mxx = lld1(tc.lds_quads, qb + 12); mxy = lld1(tc.lds_quads, qb + 16); mxz = lld1(tc.lds_quads, qb + 20);
-                    ch = __float_as_int(lld1(tc.lds_quads, qb + 24));
-                } else {
-                    mnx = gld1(gqf, (size_t)qb); mny = gld1(gqf, (size_t)qb + 4); mnz = gld1(gqf, (size_t)qb + 8);
-                    mxx = gld1(gqf, (size_t)qb + 12); mxy = gld1(gqf, (size_t)qb + 16); mxz = gld1(gqf, (size_t)qb + 20);
-                    ch = __float_as_int(gld1(gqf, (size_t)qb + 24));
-                }
-                const float x1 = (mnx - r.o.x) * ix, x2 = (mxx - r.o.x) * ix;
-                const float y1 = (mny - r.o.y) * iy, y2 = (mxy - r.o.y) * iy;
-                const float z1 = (mnz - r.o.z) * iz, z2 = (mxz - r.o.z) * iz;
-                const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
-                const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-                bool h = (tmax > tmin) && (ch != RTW_QUAD_EMPTY);
-                if (prune) h = h && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
-                if (STATS) ct.boxes += (ch != RTW_QUAD_EMPTY);
-                const unsigned long long bal = __ballot(h);
-                m = (uint32_t)(bal >> nibble_shift) & 15u;
-                c0 = __builtin_amdgcn_mov_dpp(ch, 0x00, 0xf, 0xf, true); c1 = __builtin_amdgcn_mov_dpp(ch, 0x55, 0xf, 0xf, true);
-                c2 = __builtin_amdgcn_mov_dpp(ch, 0xAA, 0xf, 0xf, true); c3 = __builtin_amdgcn_mov_dpp(ch, 0xFF, 0xf, 0xf, true);
-                need_node = false;
-            }
-            int next = -1;
-            bool full = false;
-            for (;;) {
-                if (m == 0u) {
-                    if (sp == 0) break;
-                    sp--;
-                    const uint32_t e = lldu(tc.trail, sp * tc.nthr + tc.tid);
-                    q = (int)(e >> 4); m = e & 15u;
-                    const int ch = LDSQ ? __float_as_int(lld1(tc.lds_quads, q * 32 + 24 + k4)) : __float_as_int(gld1(gqf, (size_t)q * 32 + 24 + k4));
-                    c0 = __builtin_amdgcn_mov_dpp(ch, 0x00, 0xf, 0xf, true); c1 = __builtin_amdgcn_mov_dpp(ch, 0x55, 0xf, 0xf, true);
-                    c2 = __builtin_amdgcn_mov_dpp(ch, 0xAA, 0xf, 0xf, true); c3 = __builtin_amdgcn_mov_dpp(ch, 0xFF, 0xf, 0xf, true);
-                    continue;
-                }
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1u;
-                const int ch = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-                if (ch < 0) {
-                    lstu(tc.cand, ncand * tc.nthr + tc.tid, (uint32_t)(-1 - ch));      // all four lanes store the same word
-                    ncand++;
-                    if (ncand == RTW_CAND_CAP) { full = true; break; }
-                    continue;
-                }
-                next = ch;
-                break;
-            }
-            if (next >= 0) {
-                if (m != 0u) { lstu(tc.trail, sp * tc.nthr + tc.tid, ((uint32_t)q << 4) | m); sp++; }
-                q = next; need_node = true;
-                continue;
-            }
-            if (!full) walking = false;
-            break;
-        }
-        // ---- triangle tests, four candidates at a time (lane k takes candidate j + k) ----
-        for (int j = 0; j < ncand; j += 4) {
-            const bool mine = j + k4 < ncand;
-            const int leaf = mine ? (int)lldu(tc.cand, (j + k4) * tc.nthr + tc.tid) : 0;
-            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
-            if (STATS) ct.tris += mine ? 1u : 0u;
-            int settled = -1;                    // lanes <= settled have their final verdict
-            for (;;) {
-                f3 cp = mk(0, 0, 0); float dist = 0.0f;
-                const bool acc = mine && k4 > settled && triangle_test(r, cur_dist, a, b, c, d.x, cp, dist);
-                const uint32_t am = (uint32_t)(__ballot(acc) >> nibble_shift) & 15u;
-                if (am == 0u) break;
-                const int first = __ffs((int)am) - 1;
-                cur_dist = quad_bcastf(dist, first);
-                hit_pos = mk(quad_bcastf(cp.x, first), quad_bcastf(cp.y, first), quad_bcastf(cp.z, first));
-                hit_slot = quad_bcast(leaf, first);
-                any = true;
-                settled = first;
-            }
-        }
-    }
-    return any;
-}
-
-// ---- 16-wide walk, sixteen lanes per ray ----------------------------------------------------------------
-// Same scheme as quad_walk4 with a 16-slot node per step: lane k of the group tests slot k, the hit mask is the
-// group's 16 bits of the wave ballot, candidates are triangle-tested sixteen at a time.  A ray needs ~4x fewer
-// dependent steps than with quartets, which is what matters when there are too few rays to fill the GPU.
-// EXACT: for rays that are not "tame": the reference's own box test (skipped axes, Math::Min/Max), no pruning.
-template <bool STATS, bool LDSW, bool EXACT>
-__device__ __forceinline__ bool wide_walk16(const RtwShapeDev& sh, const TravCtx& tc, const Ray& r, bool prune,
-                                            float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
-{
-    const bool skx = near_zero(r.d.x), sky = near_zero(r.d.y), skz = near_zero(r.d.z);
-    const float ix = (EXACT && skx) ? 0.0f : 1.0f / r.d.x, iy = (EXACT && sky) ? 0.0f : 1.0f / r.d.y, iz = (EXACT && skz) ? 0.0f : 1.0f / r.d.z;
-    const float eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
-    const float* gw = reinterpret_cast<const float*>(sh.wides);
-    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
-    const int k16 = tc.lane4;                                 // lane within the group of 16
-    const int grp_shift = (int)(threadIdx.x & 48u);
-    bool any = false;
-    int sp = 0;
-    uint32_t m = 0;
-    int ch_mine = 0;
-    int q = 0;
-    bool need_node = true;
-    bool walking = true;
-    while (walking) {
-        int ncand = 0;
-        for (;;) {
-            if (need_node) {
-                float mnx, mny, mnz, mxx, mxy, mxz; int ch;
-                const int wb = q * 112 + k16;
-                if (LDSW) {
-                    mnx = lld1(tc.lds_quads, wb); mny = lld1(tc.lds_quads, wb + 16); mnz = lld1(tc.lds_quads, wb + 32);
-                    mxx = lld1(tc.lds_quads, wb + 48); mxy = lld1(tc.lds_quads, wb + 64); mxz = lld1(tc.lds_quads, wb + 80);
-                    ch = __float_as_int(lld1(tc.lds_quads, wb + 96));
-                } else {
-                    mnx = gld1(gw, (size_t)wb); mny = gld1(gw, (size_t)wb + 16); mnz = gld1(gw, (size_t)wb + 32);
-                    mxx = gld1(gw, (size_t)wb + 48); mxy = gld1(gw, (size_t)wb + 64); mxz = gld1(gw, (size_t)wb + 80);
-                    ch = __float_as_int(gld1(gw, (size_t)wb + 96));
-                }
-                const float x1 = (mnx - r.o.x) * ix, x2 = (mxx - r.o.x) * ix;
-                const float y1 = (mny - r.o.y) * iy, y2 = (mxy - r.o.y) * iy;
-                const float z1 = (mnz - r.o.z) * iz, z2 = (mxz - r.o.z) * iz;
-                float tmin, tmax;
-                if (EXACT) {
-                    tmin = -FLT_MAX; tmax = FLT_MAX;
-                    if (!skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
-                    if (!sky) { tmin = ref_max(tmin, ref_min(y1, y2)); tmax = ref_min(tmax, ref_max(y1, y2)); }
-                    if (!skz) { tmin = ref_max(tmin, ref_min(z1, z2)); tmax = ref_min(tmax, ref_max(z1, z2)); }
-                } else {
-                    tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
-                    tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-                }
-                bool h = (tmax > tmin) && (ch != RTW_QUAD_EMPTY);
-                if (!EXACT && prune) h = h && !(tmin > cur_dist + (eps_t + 1.0e-4f * cur_dist)) && !(tmax < -eps_t);
-                if (STATS) ct.boxes += (ch != RTW_QUAD_EMPTY);
-                m = (uint32_t)(__ballot(h) >> grp_shift) & 0xFFFFu;
-                ch_mine = ch;
-                need_node = false;
-            }
-            int next = -1;
-            bool full = false;
-            for (;;) {
-                if (m == 0u) {
-                    if (sp == 0) break;
-                    sp--;
-                    const uint32_t e = lldu(tc.trail, sp * tc.nthr + tc.tid);
-                    q = (int)(e >> 16); m = e & 0xFFFFu;
-                    ch_mine = LDSW ? __float_as_int(lld1(tc.lds_quads, q * 112 + 96 + k16)) : __float_as_int(gld1(gw, (size_t)q * 112 + 96 + k16));
-                    continue;
-                }
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1u;
-                const int ch = __shfl(ch_mine, k, 16);
-                if (ch < 0) {
-                    lstu(tc.cand, ncand * tc.nthr + tc.tid, (uint32_t)(-1 - ch));
-                    ncand++;
-                    if (ncand == RTW_WIDE_CAND) { full = true; break; }
-                    continue;
-                }
-                next = ch;
-                break;
-            }
-            if (next >= 0) {
-                if (m != 0u) { lstu(tc.trail, sp * tc.nthr + tc.tid, ((uint32_t)q << 16) | m); sp++; }
-                q = next; need_node = true;
-                continue;
-            }
-            if (!full) walking = false;
-            break;
-        }
-        for (int j = 0; j < ncand; j += 16) {
-            const bool mine = j + k16 < ncand;
-            const int leaf = mine ? (int)lldu(tc.cand, (j + k16) * tc.nthr + tc.tid) : 0;
-            const float4 a = gld4(tr4, 4 * (size_t)leaf), b = gld4(tr4, 4 * (size_t)leaf + 1), c = gld4(tr4, 4 * (size_t)leaf + 2), d = gld4(tr4, 4 * (size_t)leaf + 3);
-            if (STATS) ct.tris += mine ? 1u : 0u;
-            int settled = -1;
-            for (;;) {
-                f3 cp = mk(0, 0, 0); float dist = 0.0f;
-                const bool acc = mine && k16 > settled && triangle_test(r, cur_dist, a, b, c, d.x, cp, dist);
-                const uint32_t am = (uint32_t)(__ballot(acc) >> grp_shift) & 0xFFFFu;
-                if (am == 0u) break;
-                const int first = __ffs((int)am) - 1;
-                cur_dist = __shfl(dist, first, 16);
-                hit_pos = mk(__shfl(cp.x, first, 16), __shfl(cp.y, first, 16), __shfl(cp.z, first, 16));
-                hit_slot = __shfl(leaf, first, 16);
-                any = true;
-                settled = first;
-            }
-        }
-    }
-    return any;
-}
+// what a helper needs to know about the lane it runs on: does this lane add the per-ray work counters?
+struct TravCtx { bool count; };
+__device__ __forceinline__ TravCtx make_trav() { TravCtx t; t.count = true; return t; }
 
 // ---- RTexture::Sample (Src/Texture.cpp:23-57) on RGBA8 texels + the host LUT ---------------------
 __device__ __forceinline__ void texel_fetch(const uint32_t* __restrict__ tex, const float* __restrict__ lut, int idx, float& r, float& g, float& b, float& a)
@@ -846,49 +467,24 @@ __device__ __forceinline__ void hit_finish(const RtwSceneDev* __restrict__ sc, c
     tri_index = -1;
 }
 
-// LPR = lanes per ray (1, or 4 in the quartet path kernel); LDSQ = shape 0's quads are staged in LDS.
-// In a quartet the four lanes run everything but quad_walk4 redundantly on identical state; Counters
-// `walk` collects what is counted per lane (box / triangle tests), `ct` what is counted once per ray.
-template <bool STATS, int LPR, bool LDSQ>
-__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, bool first_shape, const TravCtx& tc,
+// RMeshShape::TestRayIntersection for one ray per lane: the reference's own walk of the binary tree (tree_walk), then the shading inputs
+template <bool STATS>
+__device__ __forceinline__ bool mesh_query(const RtwSceneDev* __restrict__ sc, const RtwShapeDev& sh, const TravCtx& tc,
                                            const Ray& r, float seg_dist, Hit& out, int& tri_index, Counters& ct)
 {
     float cur = seg_dist; f3 pos = mk(0, 0, 0); int slot = -1;
     bool any;
     Counters walk = { 0, 0, 0, 0, 0, 0 };
-    const bool tame = ray_is_tame(r);
-    if (LPR == 16 && !tame && sc->traversal != 0 && sh.n_wides > 0) {
-        if (LDSQ && first_shape) any = wide_walk16<STATS, true, true>(sh, tc, r, false, cur, pos, slot, walk);
-        else any = wide_walk16<STATS, false, true>(sh, tc, r, false, cur, pos, slot, walk);
-        if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
-    } else
-    if (tame) {
-        if (sc->traversal != 0 && sh.n_quads > 0) {
-            if (LPR == 16 && sh.n_wides > 0) {
-                if (LDSQ && first_shape) any = wide_walk16<STATS, true, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-                else any = wide_walk16<STATS, false, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
-            } else if (LPR == 4) {
-                if (LDSQ && first_shape) any = quad_walk4<STATS, true>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-                else any = quad_walk4<STATS, false>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; walk.boxes = walk.tris = 0; }
-            } else
-                any = quad_walk<STATS>(sh, tc, r, sc->prune != 0, cur, pos, slot, walk);
-        } else {
-            any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, walk);
-        }
-    } else {
-        any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, walk);
-    }
+    if (ray_is_tame(r)) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, sc->prune != 0, cur, pos, slot, walk);
+    else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, r, false, cur, pos, slot, walk);
     if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
     if (!any) return false;
-    if (!RTW_IN_RANGE(sc, 3, slot, sh.n_tris)) return false;
     mesh_finish<STATS>(sc, sh, tc, pos, cur, slot, out, tri_index, ct);
     return true;
 }
 
 // ---- RayTracerScene::FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) ------------------------
-template <bool STATS, int LPR, bool LDSQ>
+template <bool STATS>
 __device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, const Ray& in, Hit& out, int& tri_index, Counters& ct)
 {
     int hit_shape = -1;
@@ -912,7 +508,7 @@ __device__ __forceinline__ int find_intersection(const RtwSceneDev* __restrict__
             }
             continue;
         }
-        if (mesh_query<STATS, LPR, LDSQ>(sc, sh, s == 0, tc, in, seg, out, tri_index, ct)) { seg = out.dist; hit_shape = s; }
+        if (mesh_query<STATS>(sc, sh, tc, in, seg, out, tri_index, ct)) { seg = out.dist; hit_shape = s; }
     }
     return hit_shape;
 }
@@ -970,7 +566,6 @@ __device__ __forceinline__ f3 hemisphere_direction(const RtwSceneDev* __restrict
     if (sc->debug_table_mask) idx &= (uint32_t)sc->debug_table_mask;
     const bool fetched = rng.pre_reads == rng.table_reads;
     rng.table_reads++;
-    if (!RTW_IN_RANGE(sc, 4, idx, RTW_TABLE_SIZE)) return normal;
     const float* e = sc->unit_table;
     const f3 v = fetched ? mk(rng.pre_x, rng.pre_y, rng.pre_z) : mk(gld1(e, (size_t)idx * 3), gld1(e, (size_t)idx * 3 + 1), gld1(e, (size_t)idx * 3 + 2));
     if (dot(v, normal) > 0.0f) return v;                                          // Src/Math.cpp:42-54
@@ -1100,9 +695,8 @@ struct LevelStore {
     }
 };
 
-template <bool STATS, int LPR, bool LDSQ>
-__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv,
-                         bool resume = false, int first_shape = -1, const Hit* first_hit = nullptr)
+template <bool STATS>
+__device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, Ray ray, int max_bounce, bool preview, PathRng& rng, Counters& ct, const LevelStore& lv)
 {
     int nlev = 0;
     f3 L = mk(0, 0, 0);
@@ -1110,9 +704,7 @@ __device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, 
     for (;;) {
         if (depth == 0) { L = mk(0, 0, 0); break; }
         Hit h; int tri;
-        int s;
-        if (resume) { s = first_shape; h = *first_hit; resume = false; }     // the scene query of the camera ray was done by the primary kernel
-        else s = find_intersection<STATS, LPR, LDSQ>(sc, tc, ray, h, tri, ct);
+        const int s = find_intersection<STATS>(sc, tc, ray, h, tri, ct);
         if (s < 0) {                                                     // sky (Src/RayTracerScene.cpp:89-94)
             const float t = 0.5f * (ray.d.y + 1.0f);
             L = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
@@ -1127,7 +719,6 @@ __device__ f3 trace_path(const RtwSceneDev* __restrict__ sc, const TravCtx& tc, 
             break;
         }
         const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
-        if (!RTW_IN_RANGE(sc, 5, nlev, max_bounce)) { L = mk(0, 0, 0); break; }
         if (rng.random() <= h.alpha) {
             if (all_nonzero(b.att)) {
                 lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
@@ -1318,19 +909,15 @@ __device__ __forceinline__ int work_to_pixel(const RtwRenderParams& p, int wi)
     return (j * p.world + p.rank) * per_task + r;
 }
 
-// the pass index: a launch parameter, or (replayed launch graphs) a device word that resolve_kernel advances
-__device__ __forceinline__ int pass_of(const RtwRenderParams& p) { return p.pass_ptr ? *p.pass_ptr : p.pass_index; }
-
 // ---- kernels -----------------------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
                                                      uint32_t* __restrict__ argb, float4* __restrict__ ws, RtwRenderParams p)
 {
     __shared__ float thr[256];
-    __shared__ uint32_t trav_words[RTW_TRAV_LDS_WORDS];
     thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
     __syncthreads();
-    const TravCtx tc = make_trav(trav_words);
+    const TravCtx tc = make_trav();
     const int wi = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = p.width * p.height;
     const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
@@ -1340,10 +927,10 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
         LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)wi; lv.rec_levels = 0;
         f3 c = mk(0, 0, 0);
         for (int i = 0; i < p.sub_samples; i++) {
-            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)i);
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
             const Ray ray = camera_ray(p.width, p.height, pixel, i, rng);
             if (STATS) ct.cams++;
-            c = c + trace_path<STATS, 1, false>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
+            c = c + trace_path<STATS>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
         }
         c = c / (float)p.sub_samples;
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
@@ -1351,48 +938,21 @@ __global__ __launch_bounds__(256) void render_kernel(const RtwSceneDev* __restri
     if (STATS) flush_counters(sc, ct);
 }
 
-// ======================================================================================================
-// Compacted pipeline (the default): the frame is rendered by three launches on the same stream.
-//   primary_kernel  one thread per pixel: camera rays + shape-bound tests.  Pixels whose samples all miss
-//                   every shape bound (92-97 % of a frame of the config scenes) are finished here, in one
-//                   streaming pass over the accumulator; the rest append one entry per live sample to a
-//                   path queue with one wave-aggregated atomic (ballot + popcount).
-//   path_kernel     one lane per queued path (grid-stride over the queue): the full bounce loop.
-//   resolve_kernel  one thread per pending pixel: sums its samples in sub-sample order and resolves.
-// Every float operation happens in the same order as in the one-kernel form, so both give the same bits.
-// ======================================================================================================
+// ---- the bins + wave pipeline (pipeline 3; rtw_wave_kernels.h): one pass per set of launches.  Kept as the one-pass reference the pass-batched
+// pipeline is compared with: primary_bins_kernel (+ primary_sky_kernel beside it), then per bounce one wave-per-ray trace launch and one shade
+// launch, then resolve_kernel.  A path's slot in the dense arrays = work item * sub_samples + sub-sample. ----
 struct PipeBufs {
-    uint32_t* __restrict__ queue;      // path id = work_item * 4 + sub_sample
-    uint32_t* __restrict__ pend;       // work items with at least one queued sample
-    float4* __restrict__ rad;          // radiance per path id (only slots of pending pixels are used)
-    float4* __restrict__ hitrec;       // with primary packets: 2 x float4 per path id (position + distance, shape + leaf slot)
-    uint32_t* __restrict__ counters;   // [0] queue length, [1] pending length, [4 + r] length of round r's trace list
-    float4* __restrict__ ws;           // level store of path_kernel's threads / of the wavefront pipeline's path slots
-    // wavefront pipeline (one launch per bounce): everything below is indexed by the dense path slot = queue index
-    float4* __restrict__ hitslot;      // 2 x float4 per slot: hit position + distance, shape + leaf slot
+    uint32_t* __restrict__ queue;      // round 0's trace list: the slots of the paths the primary kernel's shading step left alive
+    uint32_t* __restrict__ pend;       // work items (pixels) with at least one sample that hit something: resolve_kernel sums their samples
+    float4* __restrict__ rad;          // radiance per path id = work item * 4 + sub-sample (only slots of pending pixels are used)
+    uint32_t* __restrict__ counters;   // [0] queue length, [1] pending length, [4 + r] length of round r's trace list; [64 ..] their values at the end of the previous pass
+    float4* __restrict__ ws;           // level store: max_bounce x 3 float4 per slot
+    float4* __restrict__ hitslot;      // 2 x float4 per slot: hit position + distance, shape + leaf slot (+ "more to trace" flag with leading analytic shapes)
     float4* __restrict__ state;        // 3 x float4 per slot: origin + distance, direction + draw counter, key / table reads / levels / depth
     uint32_t* __restrict__ tlist0;     // trace lists (slots whose next segment must be traced), ping-pong
     uint32_t* __restrict__ tlist1;
     uint32_t capacity;                 // slots the dense arrays hold
-    float4* __restrict__ accum;        // the framebuffer (RtwRenderParams::resolve_inline: a path's last shading step resolves its pixel)
-    uint32_t* __restrict__ argb;
 };
-
-// like wave_push, returns the index the value was stored at (or 0xFFFFFFFF)
-__device__ __forceinline__ uint32_t wave_push_slot(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
-{
-    const unsigned long long m = __ballot(flag);
-    if (m == 0ull) return 0xFFFFFFFFu;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader);
-    if (!flag) return 0xFFFFFFFFu;
-    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    list[at] = value;
-    return at;
-}
 
 __device__ __forceinline__ void wave_push(uint32_t* __restrict__ list, uint32_t* __restrict__ counter, bool flag, uint32_t value)
 {
@@ -1412,172 +972,9 @@ __device__ __forceinline__ f3 sky_color(float dir_y)        // Src/RayTracerScen
     return mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
 }
 
-// PACKET: the camera ray's whole scene query happens here, as a packet walk of each wave's 64 neighbouring
-// pixels; only samples that HIT are queued (with their hit record), misses are finished with the sky colour.
-template <bool STATS, bool PACKET>
-__global__ __launch_bounds__(256) void primary_kernel(const RtwSceneDev* __restrict__ sc, float4* __restrict__ accum,
-                                                      uint32_t* __restrict__ argb, PipeBufs pb, RtwRenderParams p)
-{
-    __shared__ float thr[256];
-    thr[threadIdx.x] = sc->gamma_thr[threadIdx.x];
-    __syncthreads();
-    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npix = p.width * p.height;
-    const int pixel = wi < p.count ? work_to_pixel(p, wi) : npix;
-    const bool live = pixel < npix;
-    Counters ct = { 0, 0, 0, 0, 0, 0 };
-    f3 s[4];
-    float4 hr0[4], hr1[4];
-    for (int i = 0; i < 4; i++) { hr0[i] = make_float4(0.f, 0.f, 0.f, 0.f); hr1[i] = hr0[i]; }
-    uint32_t queued = 0, full_trace = 0;
-    const uint32_t phase = table_phase(p.seed);
-    const int n_shapes = sc->n_shapes;
-    const bool prune = sc->prune != 0;
-    for (int i = 0; i < 4; i++) {                            // wave-uniform loop: the packet walk needs the whole wave
-        s[i] = mk(0, 0, 0);
-        if (i >= p.sub_samples) continue;
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)pass_of(p), (uint32_t)i);
-        const Ray ray = camera_ray(p.width, p.height, live ? pixel : 0, i, rng);
-        if (STATS && live) ct.cams++;
-        if (p.max_bounce == 0) continue;                     // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
-        if (!PACKET) {
-            bool any = false;
-            for (int k = 0; k < n_shapes; k++) {
-                float t0, t1;
-                any = any || slab_exact(ray, sc->shapes[k].bmin[0], sc->shapes[k].bmin[1], sc->shapes[k].bmin[2],
-                                        sc->shapes[k].bmax[0], sc->shapes[k].bmax[1], sc->shapes[k].bmax[2], t0, t1);
-            }
-            if (live && any) queued |= 1u << i;
-            else if (live) { s[i] = sky_color(ray.d.y); if (STATS) { ct.rays++; ct.boxes += (uint32_t)n_shapes; } }
-            continue;
-        }
-        // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
-        int hit_shape = -1, hit_slot = -1;
-        f3 hit_pos = mk(0, 0, 0);
-        float seg = ray.dist;
-        if (STATS && live) ct.rays++;
-        const bool tame = ray_is_tame(ray);
-        for (int k = 0; k < n_shapes; k++) {
-            const RtwShapeDev& sh = sc->shapes[k];
-            float t0, t1;
-            const bool inbox = live && slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1);
-            if (STATS && live) ct.boxes++;
-            if (__ballot(inbox) == 0ull) continue;
-            float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
-            const bool any = packet_walk<STATS, false>(sh.nodes, sh.tris, sh.n_nodes, ray, inbox && tame, prune, cur, pos, slot, ct);
-            if (any) { seg = cur; hit_shape = k; hit_slot = slot; hit_pos = pos; }
-        }
-        if (!live) continue;
-        if (!tame) {            // a handful per frame (a direction component below FLT_EPSILON): the path kernel traces them from the camera
-            queued |= 1u << i; full_trace |= 1u << i;
-            if (STATS) { ct.rays--; ct.boxes -= (uint32_t)n_shapes; }
-            continue;
-        }
-        if (hit_shape < 0) { s[i] = sky_color(ray.d.y); continue; }
-        queued |= 1u << i;
-        if (p.wavefront) {      // the record goes to the path's dense slot, known once the sample has been queued (below)
-            hr0[i] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
-            hr1[i] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
-        } else {
-            pb.hitrec[((size_t)wi * 4 + i) * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
-            pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
-        }
-    }
-    if (live) {
-        if (queued == 0) {
-            f3 c = mk(0, 0, 0);
-            for (int i = 0; i < 4; i++) if (i < p.sub_samples) c = c + s[i];
-            c = c / (float)p.sub_samples;
-            resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
-        } else {
-            for (int i = 0; i < 4; i++)
-                if (i < p.sub_samples && !(queued & (1u << i))) pb.rad[(size_t)wi * 4 + i] = make_float4(s[i].x, s[i].y, s[i].z, 0.0f);
-        }
-    }
-    // bit 31 of a queue entry: no hit record, trace the path from the camera ray
-    for (int i = 0; i < 4; i++) {
-        const uint32_t at = wave_push_slot(pb.queue, &pb.counters[0], (queued >> i) & 1u, ((uint32_t)wi * 4u + (uint32_t)i) | (((full_trace >> i) & 1u) << 31));
-        if (PACKET && p.wavefront && at != 0xFFFFFFFFu && at < pb.capacity) { pb.hitslot[(size_t)at * 2] = hr0[i]; pb.hitslot[(size_t)at * 2 + 1] = hr1[i]; }
-    }
-    wave_push(pb.pend, &pb.counters[1], queued != 0, (uint32_t)wi);
-    if (STATS) flush_counters(sc, ct);
-}
-
-// One owner per queued path: a quartet (LPR = 4 lanes on one ray) or a single lane (LPR = 1); NT threads per block.
-// With LDSQ the block first stages every quad of shape 0 (breadth-first array) in LDS.  When the primary kernel has
-// already done the camera ray's scene query (p.packets), the path resumes from the stored hit record.
-template <bool STATS, bool LDSQ, int NT, int LPR, int MINW = (LPR == 16 ? 4 : (NT <= 256 ? 4 : 2))>
-__global__ __launch_bounds__(NT, MINW) void path_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int lds_quad_count)
-{
-    __shared__ uint32_t trav_words[(LPR == 16 ? (RTW_WIDE_STACK + RTW_WIDE_CAND) : (RTW_QUAD_STACK + RTW_CAND_CAP)) * (NT / LPR)];
-    HIP_DYNAMIC_SHARED(float, lds_quads);
-    // the grid is sized for the worst case (every sample queued); blocks past the real queue leave at once
-    if (blockIdx.x * (uint32_t)(NT / LPR) >= pb.counters[0]) return;
-#ifdef RTW_TIMING
-    const unsigned long long rtw_t0 = wall_clock64();
-#endif
-    if (LDSQ) {     // lds_quad_count nodes of shape 0: quads (8 float4 each) or 16-wide nodes (28 float4 each)
-        const float4* src = LPR == 16 ? reinterpret_cast<const float4*>(sc->shapes[0].wides) : reinterpret_cast<const float4*>(sc->shapes[0].quads);
-        float4* dst = reinterpret_cast<float4*>(lds_quads);
-        for (int i = (int)threadIdx.x; i < lds_quad_count * (LPR == 16 ? 28 : 8); i += NT) dst[i] = gld4(src, (size_t)i);
-        __syncthreads();
-    }
-    TravCtx tc;
-    if (LPR == 16) tc = make_trav16(trav_words, NT, LDSQ ? lds_quads : nullptr);
-    else if (LPR == 4) tc = make_trav4(trav_words, NT, LDSQ ? lds_quads : nullptr);
-    else { tc = make_trav(trav_words); tc.nthr = NT; }
-    const uint32_t n = pb.counters[0];
-    const uint32_t nowners = gridDim.x * (NT / LPR);
-    const uint32_t go = blockIdx.x * (NT / LPR) + (threadIdx.x / LPR);
-    const int npix = p.width * p.height;
-    const uint32_t phase = table_phase(p.seed);
-    Counters ct = { 0, 0, 0, 0, 0, 0 };
-    LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)nowners; lv.tid = (size_t)go; lv.rec_levels = 0;
-    for (uint32_t q = go; q < n; q += nowners) {
-        const uint32_t qe = pb.queue[q];
-        const uint32_t pid = qe & 0x7FFFFFFFu;
-        const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
-        const int pixel = work_to_pixel(p, wi);
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)sub);
-        const Ray ray = camera_ray(p.width, p.height, pixel, sub, rng);
-        f3 L;
-        if (p.packets && !(qe >> 31)) {
-            const float4 r0 = pb.hitrec[(size_t)pid * 2], r1 = pb.hitrec[(size_t)pid * 2 + 1];
-            const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
-            Hit h; int tri_index;
-            mesh_finish<STATS>(sc, sc->shapes[hs], tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
-            L = trace_path<STATS, LPR, LDSQ>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv, true, hs, &h);
-        } else {
-            L = trace_path<STATS, LPR, LDSQ>(sc, tc, ray, p.max_bounce, p.preview != 0, rng, ct, lv);
-        }
-        if (LPR == 1 || tc.lane4 == 0) pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
-    }
-#ifdef RTW_TIMING
-    {
-        unsigned mb = ct.boxes, mt = ct.tris, sb = ct.boxes, mr = ct.rays;
-        for (int o = 32; o > 0; o >>= 1) { mb = max(mb, (unsigned)__shfl_xor((int)mb, o)); mt = max(mt, (unsigned)__shfl_xor((int)mt, o)); sb += (unsigned)__shfl_xor((int)sb, o); mr = max(mr, (unsigned)__shfl_xor((int)mr, o)); }
-        if ((threadIdx.x & 63u) == 0 && blockIdx.x * (NT / 64) + (threadIdx.x >> 6) < 16384) {
-            const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-            g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = mb; g_rtw_timing[6 * w + 3] = mt; g_rtw_timing[6 * w + 4] = sb; g_rtw_timing[6 * w + 5] = mr;
-        }
-    }
-#endif
-    if (STATS) flush_counters(sc, ct);
-}
-
-// ======================================================================================================
-// Wavefront pipeline: one launch per bounce instead of one kernel that carries every path to its end.
-//   shade_kernel  ONE lane per path (the shading step is a chain of dependent loads, not arithmetic): shading
-//                 inputs of the recorded hit, material bounce, alpha test, level push; a path that continues
-//                 saves its ray and joins the next trace list, a path that ends folds its levels and writes
-//                 its radiance.  Round 0 regenerates the camera ray of each queued sample.
-//   trace_kernel  SIXTEEN lanes per ray: FindIntersectionWithScene of the saved ray on the 16-wide tree, result
-//                 written as a hit record.  Only the rays that are still alive are launched (dense lists).
-// Every float operation is the one the single-kernel forms execute, in the same order.
-// ======================================================================================================
 __device__ __forceinline__ const uint32_t* wf_list(const PipeBufs& pb, int which) { return which ? pb.tlist1 : pb.tlist0; }
 
-// direct slots (p.direct_slots): slot q = work item * sub_samples + sub-sample  <->  path id = work item * 4 + sub-sample
+// slot q = work item * sub_samples + sub-sample  <->  path id = work item * 4 + sub-sample
 __device__ __forceinline__ uint32_t slot_of_path(const RtwRenderParams& p, uint32_t wi, uint32_t sub) { return wi * (uint32_t)p.sub_samples + sub; }
 __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32_t q)
 {
@@ -1589,74 +986,49 @@ __device__ __forceinline__ uint32_t pid_of_slot(const RtwRenderParams& p, uint32
     }
 }
 
-// End of the pass's last kernel (whole blocks call it after their work).  The last block to finish files the counters for the host
-// (queue lengths, sizes of the next launches), zeroes them for the next pass (which saves that pass a memset launch) and advances the
-// pass index of a replayed launch graph.  Every block has read what it needs of both before it takes its ticket.
-__device__ __forceinline__ void pass_epilogue(const PipeBufs& pb, const RtwRenderParams& p, uint32_t n_blocks)      // n_blocks: the blocks that call this
-{
-    if (p.self_clean) {
-        __shared__ uint32_t last_block;
-        __syncthreads();
-        if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == n_blocks - 1u ? 1u : 0u;
-        __syncthreads();
-        if (last_block && threadIdx.x < 64) {
-            const uint32_t v = threadIdx.x == 40 ? 0u : pb.counters[threadIdx.x];
-            pb.counters[64 + threadIdx.x] = v;
-            pb.counters[threadIdx.x] = 0u;
-        }
-        if (last_block && threadIdx.x == 0 && p.pass_ptr) *p.pass_ptr += 1;        // every other block is done with the pass index
-    } else if (p.pass_ptr && blockIdx.x == 0 && threadIdx.x == 0) {
-        *p.pass_ptr += 1;           // (resolve_kernel only: nothing in it reads the pass index)
-    }
-}
-
 // RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94) for one path whose segment has just been traced: shade the
 // recorded hit (r0 = position + distance, r1 = shape + leaf slot; shape < 0 = the segment missed), push a level, set up
 // the next segment; or finish the path (fold the levels back in the reference's association order, write the radiance).
-// have_hit false: nothing to shade yet (the segment still has to be traced).  Returns true when the path goes on: its
-// state is then saved in slot q.
+// Returns true when the path goes on: its state is then saved in slot q.
 template <bool STATS, bool AN>
 __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ sc, const PipeBufs& pb, const RtwRenderParams& p, uint32_t q, uint32_t pid,
-                                               Ray ray, PathRng rng, int depth, int nlev, bool have_hit, float4 r0, float4 r1, Counters& ct,
-                                               const float* __restrict__ thr)      // the block's gamma staircase in LDS (used with resolve_inline)
+                                               Ray ray, PathRng rng, int depth, int nlev, float4 r0, float4 r1, Counters& ct)
 {
-    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
+    const TravCtx tc = make_trav();
     if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
     LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
     f3 L = mk(0, 0, 0);
     bool done = false;
-    if (have_hit) {
-        const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
-        if (hs < 0) { L = sky_color(ray.d.y); done = true; }
+    const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
+    if (hs < 0) { L = sky_color(ray.d.y); done = true; }
+    else {
+        const RtwShapeDev& sh = sc->shapes[hs];
+        Hit h; int tri_index;
+        if (AN) hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+        else mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
+        if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
         else {
-            const RtwShapeDev& sh = sc->shapes[hs];
-            Hit h; int tri_index;
-            if (AN) hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
-            else mesh_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
-            if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
-            else {
-                Ray out = ray;
-                if (p.preview) {
-                    const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
-                    L = mk(0, 0, 0) + pv.att * h.color; done = true;
-                } else {
-                    const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
-                    if (rng.random() <= h.alpha) {
-                        if (all_nonzero(b.att)) {
-                            lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
-                            lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
-                            lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
-                            nlev++;
-                            ray = out;
-                        } else { L = mk(0, 0, 0) + b.em; done = true; }
-                    } else {
-                        lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+            Ray out = ray;
+            if (p.preview) {
+                const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
+                L = mk(0, 0, 0) + pv.att * h.color; done = true;
+            } else {
+                const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
+                if (rng.random() <= h.alpha) {
+                    if (all_nonzero(b.att)) {
+                        lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
+                        lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                        lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
                         nlev++;
-                        const float rd = ray.dist - h.dist;
-                        ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
-                    }
-                    if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
+                        ray = out;
+                    } else { L = mk(0, 0, 0) + b.em; done = true; }
+                } else {
+                    lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
+                    nlev++;
+                    const float rd = ray.dist - h.dist;
+                    ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
                 }
+                if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
             }
         }
     }
@@ -1670,10 +1042,6 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
                 L = mk(0, 0, 0) + L;
             }
         }
-        if (p.resolve_inline) {     // the pixel's only sample: c = (0 + s[0]) / 1, then AccumulatePixel::AddPixel + GetGammaSpacePixel
-            resolve_pixel(thr, pb.accum, pb.argb, work_to_pixel(p, (int)(pid >> 2)), mk(0, 0, 0) + L, p.preview != 0);
-            return false;
-        }
         pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
         return false;
     }
@@ -1683,8 +1051,8 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
                                               __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
     if (AN && p.lead_shapes > 0) {  // the scene's leading spheres / planes / capsules: tested here, a ray per lane (in the trace kernel a whole
                                     // wave would repeat each test 64 times); the record is where the trace of this segment starts from
-        int hs = -1, hslot = -1; f3 hp = mk(0, 0, 0); float seg = ray.dist;
-        lead_find<STATS>(sc, p.lead_shapes, ray, seg, hs, hslot, hp, ct);
+        int hs2 = -1, hslot = -1; f3 hp = mk(0, 0, 0); float seg = ray.dist;
+        lead_find<STATS>(sc, p.lead_shapes, ray, seg, hs2, hslot, hp, ct);
         // can a later shape be hit at all?  Only if the ray's line meets its culling box (the reference's own early-out,
         // Src/RayTracerScene.cpp:109; a plane has none).  If no box is met the record above is the query's result.
         // With pruning on, a tame ray whose segment [0, seg] ends before the box or starts past it cannot be accepted by anything
@@ -1705,20 +1073,18 @@ __device__ __forceinline__ bool shade_hit_step(const RtwSceneDev* __restrict__ s
         }
         if (STATS && !more) { ct.rays++; ct.boxes += tested; }       // (a ray that goes on to the trace kernel is counted there)
         pb.hitslot[(size_t)q * 2] = make_float4(hp.x, hp.y, hp.z, seg);
-        pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(more ? 1 : 0), 0.0f);
+        pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs2), __int_as_float(hslot), __int_as_float(more ? 1 : 0), 0.0f);
     }
     return true;
 }
 
+// round >= 1: the paths of trace list (round - 1) have had their segment traced (the primary kernel was round 0)
 template <bool STATS, bool AN>
-__global__ __launch_bounds__(256, 3) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int last)
+__global__ __launch_bounds__(256, 3) void shade_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
-    __shared__ float thr[256];
-    if (p.resolve_inline) { thr[threadIdx.x] = sc->gamma_thr[threadIdx.x]; __syncthreads(); }
-    // the round's input list: round 0 = the path queue itself; with direct slots the queue is round 0's TRACE list (round 1's input)
-    const bool from_queue = p.direct_slots && round == 1;
-    const uint32_t n = (round == 0 || from_queue) ? pb.counters[0] : pb.counters[4 + round - 1];
-    const uint32_t* __restrict__ src = round == 0 ? nullptr : (from_queue ? pb.queue : wf_list(pb, (round - 1) & 1));
+    const bool from_queue = round == 1;         // the queue is round 0's trace list
+    const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round - 1];
+    const uint32_t* __restrict__ src = from_queue ? pb.queue : wf_list(pb, (round - 1) & 1);
     uint32_t* __restrict__ dst = round & 1 ? pb.tlist1 : pb.tlist0;
     const uint32_t nthreads = gridDim.x * blockDim.x;
     const int npix = p.width * p.height;
@@ -1727,87 +1093,23 @@ __global__ __launch_bounds__(256, 3) void shade_kernel(const RtwSceneDev* __rest
     const uint32_t rounds_of_wave = (n + nthreads - 1) / nthreads;       // wave-uniform trip count: every lane joins the pushes
     for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < rounds_of_wave; it++, k += nthreads) {
         const bool live = k < n;
-        const uint32_t q = live ? (round == 0 ? k : src[k]) : 0u;
+        const uint32_t q = live ? src[k] : 0u;
         bool go_on = false;                                                // this path has another segment to trace
         if (live && q < pb.capacity) {
-            const uint32_t qe = p.direct_slots ? pid_of_slot(p, q) : pb.queue[q];
-            const uint32_t pid = qe & 0x7FFFFFFFu;
+            const uint32_t pid = pid_of_slot(p, q);
             const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
             const int pixel = work_to_pixel(p, wi);
-            PathRng rng; Ray ray; int depth, nlev;
-            bool have_hit = true;
-            if (round == 0) {
-                rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)sub);
-                ray = camera_ray(p.width, p.height, pixel, sub, rng);
-                depth = p.max_bounce; nlev = 0;
-                if (qe >> 31) have_hit = false;                            // untame camera ray: its first segment is traced like any other
-            } else {
-                const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1], s2 = pb.state[(size_t)q * 3 + 2];
-                ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
-                rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
-                rng.table_base = (((uint64_t)pass_of(p) * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
-                nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
-                rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
-            }
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-            if (have_hit) {
-                // round 0 of the bins + wave pipeline: its primary kernel files hit records under the path id, not the slot
-                const size_t rec = (round == 0 && p.wavefront == 2) ? (size_t)pid : (size_t)q;
-                r0 = pb.hitslot[rec * 2]; r1 = pb.hitslot[rec * 2 + 1];
-            }
-            go_on = shade_hit_step<STATS, AN>(sc, pb, p, q, pid, ray, rng, depth, nlev, have_hit, r0, r1, ct, thr);
+            PathRng rng; Ray ray;
+            const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1], s2 = pb.state[(size_t)q * 3 + 2];
+            ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
+            rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
+            rng.table_base = (((uint64_t)p.pass_index * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
+            const int nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu), depth = (int)(__float_as_uint(s2.z) >> 16);
+            rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
+            const float4 r0 = pb.hitslot[(size_t)q * 2], r1 = pb.hitslot[(size_t)q * 2 + 1];
+            go_on = shade_hit_step<STATS, AN>(sc, pb, p, q, pid, ray, rng, depth, nlev, r0, r1, ct);
         }
         wave_push(dst, &pb.counters[4 + round], go_on, q);
-    }
-    if (STATS) flush_counters(sc, ct);
-    if (last) pass_epilogue(pb, p, gridDim.x);     // resolve_inline: this is the pass's last launch
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(256) void trace_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
-{
-    __shared__ uint32_t trav_words[(RTW_WIDE_STACK + RTW_WIDE_CAND) * 16];
-    const uint32_t n = pb.counters[4 + round];
-    if (blockIdx.x * 16u >= n) return;
-    const uint32_t* __restrict__ src = wf_list(pb, round & 1);
-    const TravCtx tc = make_trav16(trav_words, 256, nullptr);
-    const uint32_t ngroups = gridDim.x * 16u;
-    Counters ct = { 0, 0, 0, 0, 0, 0 };
-    const bool prune = sc->prune != 0;
-    for (uint32_t k = blockIdx.x * 16u + (threadIdx.x >> 4); k < n; k += ngroups) {
-        const uint32_t q = src[k];
-        const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1];
-        Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
-        // FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) without the shading tail: only the record of
-        // the last shape that hit is ever read, and a shape's tail does not influence the next shape's query
-        int hit_shape = -1, hit_slot = -1;
-        f3 hit_pos = mk(0, 0, 0);
-        float seg = ray.dist;
-        if (STATS && tc.count) ct.rays++;
-        const bool tame = ray_is_tame(ray);
-        for (int s = 0; s < sc->n_shapes; s++) {
-            const RtwShapeDev& sh = sc->shapes[s];
-            float t0, t1;
-            if (STATS && tc.count) ct.boxes++;
-            if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
-            float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
-            bool any;
-            Counters walk = { 0, 0, 0, 0, 0, 0 };
-            if (sh.n_wides > 0 && sc->traversal != 0) {
-                if (tame) any = wide_walk16<STATS, false, false>(sh, tc, ray, prune, cur, pos, slot, walk);
-                else any = wide_walk16<STATS, false, true>(sh, tc, ray, false, cur, pos, slot, walk);
-                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
-            } else {
-                if (tame) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, prune, cur, pos, slot, walk);
-                else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, false, cur, pos, slot, walk);
-                if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
-            }
-            if (any) { seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos; }
-        }
-        if (tc.lane4 == 0) {
-            pb.hitslot[(size_t)q * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
-            pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), 0.0f, 0.0f);
-        }
     }
     if (STATS) flush_counters(sc, ct);
 }
@@ -1836,22 +1138,31 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RtwSceneDev* __restr
         c = c / (float)p.sub_samples;
         resolve_pixel(thr, accum, argb, pixel, c, p.preview != 0);
     }
-    pass_epilogue(pb, p, gridDim.x);
+    // the pass's last kernel: the last block to finish files the counters for the host (queue lengths size the next pass's launches) and zeroes them
+    // for the next pass (which saves it a memset launch).  Every block has read what it needs of them before it takes its ticket.
+    __shared__ uint32_t last_block;
+    __syncthreads();
+    if (threadIdx.x == 0) last_block = atomicAdd(&pb.counters[40], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (last_block && threadIdx.x < 64) {
+        const uint32_t v = threadIdx.x == 40 ? 0u : pb.counters[threadIdx.x];
+        pb.counters[64 + threadIdx.x] = v;
+        pb.counters[threadIdx.x] = 0u;
+    }
 }
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void closest_kernel(const RtwSceneDev* __restrict__ sc, const float* __restrict__ rays, long long n,
                                                       float* __restrict__ hits11, int* __restrict__ shape, int* __restrict__ tri)
 {
-    __shared__ uint32_t trav_words[RTW_TRAV_LDS_WORDS];
-    const TravCtx tc = make_trav(trav_words);
+    const TravCtx tc = make_trav();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r; r.o = mk(rays[i * 7], rays[i * 7 + 1], rays[i * 7 + 2]); r.d = mk(rays[i * 7 + 3], rays[i * 7 + 4], rays[i * 7 + 5]); r.dist = rays[i * 7 + 6];
     Hit h; h.pos = mk(0, 0, 0); h.normal = mk(0, 0, 0); h.dist = 0.0f; h.color = mk(1, 1, 1); h.alpha = 1.0f;   // RayHitResult()
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     int t = -1;
-    const int s = find_intersection<STATS, 1, false>(sc, tc, r, h, t, ct);
+    const int s = find_intersection<STATS>(sc, tc, r, h, t, ct);
     float* o = hits11 + i * 11;
     o[0] = h.pos.x; o[1] = h.pos.y; o[2] = h.pos.z; o[3] = h.normal.x; o[4] = h.normal.y; o[5] = h.normal.z; o[6] = h.dist;
     o[7] = h.color.x; o[8] = h.color.y; o[9] = h.color.z; o[10] = h.alpha;
@@ -1864,8 +1175,7 @@ __global__ __launch_bounds__(256) void ray_trace_kernel(const RtwSceneDev* __res
                                                         const uint32_t* __restrict__ keys2, long long n, int max_bounce, int preview,
                                                         uint32_t seed, unsigned long long npix, float* __restrict__ rgb, float4* __restrict__ ws)
 {
-    __shared__ uint32_t trav_words[RTW_TRAV_LDS_WORDS];
-    const TravCtx tc = make_trav(trav_words);
+    const TravCtx tc = make_trav();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r; r.o = mk(rays[i * 7], rays[i * 7 + 1], rays[i * 7 + 2]); r.d = mk(rays[i * 7 + 3], rays[i * 7 + 4], rays[i * 7 + 5]); r.dist = rays[i * 7 + 6];
@@ -1873,7 +1183,7 @@ __global__ __launch_bounds__(256) void ray_trace_kernel(const RtwSceneDev* __res
     const uint32_t pixel = keys2[i * 2], sample = keys2[i * 2 + 1];
     PathRng rng; rng_init(rng, seed, table_phase(seed), npix, pixel, sample / 4u, sample % 4u);
     LevelStore lv; lv.ws = ws; lv.stride = (size_t)gridDim.x * blockDim.x; lv.tid = (size_t)i; lv.rec_levels = 0;
-    const f3 c = trace_path<STATS, 1, false>(sc, tc, r, max_bounce, preview != 0, rng, ct, lv);
+    const f3 c = trace_path<STATS>(sc, tc, r, max_bounce, preview != 0, rng, ct, lv);
     rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
     if (STATS) flush_counters(sc, ct);
 }
@@ -1946,25 +1256,21 @@ int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, cons
 
 size_t pipeline_workspace_bytes(long long work_items, int max_bounce, PipelineLayout* out)
 {
-    // queue | pend | counters | rad | level store
+    // queue | pend | counters | rad | per-slot arrays: hit records, state, trace lists, level store (a slot per possible path: work items x 4)
     const size_t n = (size_t)(work_items > 0 ? work_items : 1);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     PipelineLayout l;
-    l.path_quartets = n * 4 < (size_t)RTW_MAX_PATH_QUARTETS ? (int)(n * 4) : RTW_MAX_PATH_QUARTETS;   // one quartet per path, capped
+    l.capacity = n * 4;
     l.queue_off = 0;
-    l.pend_off = l.queue_off + up(n * 4 * 4);
+    l.pend_off = l.queue_off + up(l.capacity * 4);
     l.counters_off = l.pend_off + up(n * 4);
     l.rad_off = l.counters_off + 1024;      // 64 counters | 64 words: their values at the end of the previous pass (read back by the host) | spare
-    l.hit_off = l.rad_off + up(n * 4 * 16);
-    l.ws_off = l.hit_off + up(n * 4 * 32);
-    l.total = l.ws_off + ((size_t)l.path_quartets + 256) * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
-    // wavefront pipeline: dense per-slot arrays for every possible path (n * 4), level store included
-    l.wf_capacity = n * 4;
-    l.wf_state_off = up(l.total);
-    l.wf_tlist0_off = l.wf_state_off + up(l.wf_capacity * 48);
-    l.wf_tlist1_off = l.wf_tlist0_off + up(l.wf_capacity * 4);
-    l.wf_ws_off = l.wf_tlist1_off + up(l.wf_capacity * 4);
-    l.wf_total = l.wf_ws_off + l.wf_capacity * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
+    l.hit_off = l.rad_off + up(l.capacity * 16);
+    l.state_off = l.hit_off + up(l.capacity * 32);
+    l.tlist0_off = l.state_off + up(l.capacity * 48);
+    l.tlist1_off = l.tlist0_off + up(l.capacity * 4);
+    l.ws_off = l.tlist1_off + up(l.capacity * 4);
+    l.total = l.ws_off + l.capacity * (size_t)(max_bounce > 0 ? max_bounce : 1) * 3 * 16;
     if (out) *out = l;
     return l.total;
 }
@@ -1976,7 +1282,9 @@ size_t pipeline_counters_offset(long long work_items, int max_bounce)
     return l.counters_off;
 }
 
-int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, int lds_quad_count, const PipelineTuning& tune, bool stats, hipStream_t stream)
+// One pass through the bins + wave pipeline: primary_bins_kernel (+ primary_sky_kernel on the second stream), then trace(r - 1) / shade(r) for
+// r = 1 .. max_bounce - 1 (the primary kernel was shade(0)), then resolve_kernel.
+int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void* workspace, const RtwRenderParams& p, const PipelineTuning& tune, bool stats, hipStream_t stream)
 {
     if (p.count <= 0) return 0;
     PipelineLayout l;
@@ -1984,34 +1292,28 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
     char* w = (char*)workspace;
     PipeBufs pb;
     pb.queue = (uint32_t*)(w + l.queue_off); pb.pend = (uint32_t*)(w + l.pend_off); pb.counters = (uint32_t*)(w + l.counters_off);
-    pb.rad = (float4*)(w + l.rad_off); pb.hitrec = (float4*)(w + l.hit_off); pb.ws = (float4*)(w + l.ws_off);
+    pb.rad = (float4*)(w + l.rad_off); pb.hitslot = (float4*)(w + l.hit_off); pb.state = (float4*)(w + l.state_off);
+    pb.tlist0 = (uint32_t*)(w + l.tlist0_off); pb.tlist1 = (uint32_t*)(w + l.tlist1_off); pb.ws = (float4*)(w + l.ws_off); pb.capacity = (uint32_t)l.capacity;
     hipError_t e = hipSuccess;
     if (!tune.counters_clean) e = hipMemsetAsync(pb.counters, 0, 256, stream);     // else: the previous pass's resolve_kernel left them zeroed
     if (e != hipSuccess) return (int)e;
-    pb.hitslot = pb.hitrec; pb.state = nullptr; pb.tlist0 = pb.tlist1 = nullptr; pb.capacity = 0;
-    pb.accum = (float4*)accum; pb.argb = (uint32_t*)argb;
-    if (p.wavefront) {
-        pb.state = (float4*)(w + l.wf_state_off); pb.tlist0 = (uint32_t*)(w + l.wf_tlist0_off); pb.tlist1 = (uint32_t*)(w + l.wf_tlist1_off);
-        pb.ws = (float4*)(w + l.wf_ws_off); pb.capacity = (uint32_t)l.wf_capacity;
-    }
-    // Path owners (quartets / groups / lanes) to launch.  The true queue length is only known on the device;
-    // the host passes the length the previous pass had (frames of a progressive render barely differ) plus a
-    // margin.  Any shortfall is absorbed by the owners' stride loop, any excess by blocks that exit at once.
-    int owners = l.path_quartets;
+    // Paths to size the launches for.  The true queue length is only known on the device; the host passes the length the previous pass had
+    // (frames of a progressive render barely differ) plus a margin.  Any shortfall is absorbed by stride loops, any excess by blocks that exit at once.
+    long long owners = (long long)l.capacity;
     if (tune.expected_paths >= 0) {
-        long long want = (long long)tune.expected_paths + tune.expected_paths / 4 + 1024;
-        if (want < owners) owners = (int)want;
+        const long long want = (long long)tune.expected_paths + tune.expected_paths / 4 + 1024;
+        if (want < owners) owners = want;
     }
     const int block = 256;
     const int grid = (p.count + block - 1) / block;
     int resolve_blocks = grid < 1024 ? grid : 1024;
-    if (p.wavefront == 2 && tune.expected_paths >= 0) {      // a thread per pending pixel (at most one per queued path), not per pixel of the frame
+    if (tune.expected_paths >= 0) {      // a thread per pending pixel (at most one per queued path), not per pixel of the frame
         const int want = (tune.expected_paths + tune.expected_paths / 4 + 1024 + 255) / 256;
         if (want < resolve_blocks) resolve_blocks = want;
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[0], stream);
     bool forked = false;
-    if (p.wavefront == 2) {
+    {
         RtwRenderParams ph = p;
         if (tune.aux_stream && p.tile_order && tune.sky_job0 > 0 && tune.sky_job0 < p.n_jobs && !stats) {
             // sky-only tiles on the second stream, beside everything else of this pass
@@ -2019,224 +1321,69 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
             if (forked) {
                 const int sky_jobs = p.n_jobs - tune.sky_job0;
                 int sgrid = (sky_jobs + 3) / 4;
-                if (sgrid > tune.wave_blocks * tune.primary_blocks_per_cu) sgrid = tune.wave_blocks * tune.primary_blocks_per_cu;
+                if (sgrid > tune.cu_count * 64) sgrid = tune.cu_count * 64;
                 hipLaunchKernelGGL(primary_sky_kernel, dim3(sgrid), dim3(block), 0, tune.aux_stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, p, tune.sky_job0);
                 if (tune.do_join) (void)hipEventRecord(tune.join_event, tune.aux_stream);
                 else if (tune.aux_unjoined) *tune.aux_unjoined = true;
                 ph.n_jobs = tune.sky_job0;
             }
         }
-        const RtwRenderParams& p = ph;      // the bins kernel takes the jobs the sky kernel does not
-        const int jobs_grid = p.tile_order ? (p.n_jobs + 3) / 4 : grid;        // a wave per job (a tile, or a tile's sub-sample)
-        const int pgrid = jobs_grid < tune.wave_blocks * tune.primary_blocks_per_cu ? jobs_grid : tune.wave_blocks * tune.primary_blocks_per_cu;      // else waves take jobs in turn
+        const int jobs_grid = ph.tile_order ? (ph.n_jobs + 3) / 4 : grid;        // a wave per job (a tile, or a tile's sub-sample); else waves take jobs in turn
+        const int pgrid = jobs_grid < tune.cu_count * 64 ? jobs_grid : tune.cu_count * 64;
         if (tune.has_analytic) {
-            if (stats) hipLaunchKernelGGL((primary_bins_kernel<true, true>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-            else hipLaunchKernelGGL((primary_bins_kernel<false, true>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+            if (stats) hipLaunchKernelGGL((primary_bins_kernel<true, true>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, ph);
+            else hipLaunchKernelGGL((primary_bins_kernel<false, true>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, ph);
         } else {
-            if (stats) hipLaunchKernelGGL((primary_bins_kernel<true, false>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-            else hipLaunchKernelGGL((primary_bins_kernel<false, false>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+            if (stats) hipLaunchKernelGGL((primary_bins_kernel<true, false>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, ph);
+            else hipLaunchKernelGGL((primary_bins_kernel<false, false>), dim3(pgrid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, ph);
         }
-    } else if (p.packets) {
-        if (stats) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-        else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-    } else {
-        if (stats) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
-        else hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[1], stream);
-    if (p.wavefront == 2 && !tune.wave_fused) {
-        // shade(0), then trace(r) / shade(r + 1) for r = 0 .. max_bounce - 2: every queued path has a hit record, the last shade
-        // step sees depth 0.  Trace rounds: a wave per ray, persistent blocks (one per CU when shape 0 is staged in LDS).
-        auto items_of = [&](int round) {
-            if (p.direct_slots && round <= 1) return (long long)owners;      // the queue is round 0's trace list = round 1's input
-            long long items = round == 0 ? owners : (tune.round_hint[round - 1] >= 0 ? (long long)tune.round_hint[round - 1] + tune.round_hint[round - 1] / 4 + 256 : owners);
-            return items > owners ? (long long)owners : items;
-        };
-        for (int r = p.direct_slots ? 1 : 0; r < p.max_bounce; r++) {      // direct slots: the primary kernel was shade(0)
-            if (r > 0 && !tune.skip_trace) {
-                const long long rays = items_of(r);
-                const int stage = tune.wave_stage;
-#define RTW_LAUNCH_TW(ST, NTV)                                                                                                                  \
-                do {                                                                                                                            \
-                    long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);                                                                      \
-                    if (blocks < 1) blocks = 1;                                                                                                 \
-                    if (blocks > (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? tune.wave_blocks_mul : 1)) blocks = (long long)tune.wave_blocks * (1024 / NTV) * (ST == 0 ? tune.wave_blocks_mul : 1); \
-                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4 + (ST == 0 ? 0 : tune.wave_stage_bytes);                     \
-                    if (stats) { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<true, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                        hipLaunchKernelGGL((trace_wave_kernel<true, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
-                    else { if (dyn > 65536) (void)hipFuncSetAttribute((const void*)trace_wave_kernel<false, ST, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                        hipLaunchKernelGGL((trace_wave_kernel<false, ST, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1); } \
-                } while (0)
-                if (tune.finish_in_trace && r == p.max_bounce - 1) {      // the last round: the trace waves finish their paths, no shade launch follows
-                    constexpr int NTV = 1024;   // big blocks: the blocks that had rays take a ticket each at the end (pass_epilogue), so there should be few
-                    long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);
-                    const long long cap = (long long)tune.wave_blocks * tune.wave_blocks_mul;
-                    if (blocks < 1) blocks = 1;
-                    if (blocks > cap) blocks = cap;
-                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
-                    hipLaunchKernelGGL((trace_wave_kernel<false, 0, NTV, false, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, p.resolve_inline ? 1 : 0);
-                    break;
-                }
-#ifndef RTW_LEAD_CHUNK_SHIFT_MAX
-#define RTW_LEAD_CHUNK_SHIFT_MAX 2      /* measured on SetupScene: 4 entries per wave at a time 1.64 ms, 16: 1.67, 64: 1.84, 1: 1.80 (flagged rays cluster: small chunks spread them over the waves) */
-#endif
-                if (p.lead_shapes > 0) {        // leading analytic shapes: the records are half done, most rays need no trace (see trace_wave_lead_kernel)
-                    constexpr int NTV = 128;
-                    int shift = 0;
-                    while (shift < RTW_LEAD_CHUNK_SHIFT_MAX && (rays >> (shift + 1)) >= 16384) shift++;
-                    long long blocks = ((rays >> shift) + NTV / 64) / (NTV / 64);
-                    const long long cap = (long long)tune.wave_blocks * (1024 / NTV) * tune.wave_blocks_mul;
-                    if (blocks < 1) blocks = 1;
-                    if (blocks > cap) blocks = cap;
-                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
-                    if (stats) hipLaunchKernelGGL((trace_wave_lead_kernel<true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
-                    else hipLaunchKernelGGL((trace_wave_lead_kernel<false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
-                } else if (tune.has_analytic) { // analytic shapes somewhere after a mesh: the general wave-per-ray query
-                    constexpr int NTV = 128;
-                    long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);
-                    const long long cap = (long long)tune.wave_blocks * (1024 / NTV) * tune.wave_blocks_mul;
-                    if (blocks < 1) blocks = 1;
-                    if (blocks > cap) blocks = cap;
-                    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
-                    if (stats) hipLaunchKernelGGL((trace_wave_kernel<true, 0, NTV, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
-                    else hipLaunchKernelGGL((trace_wave_kernel<false, 0, NTV, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
-                } else
-                if (stage == 0 && tune.trace_block == 64) RTW_LAUNCH_TW(0, 64); else if (stage == 0 && tune.trace_block == 128) RTW_LAUNCH_TW(0, 128); else if (stage == 0) RTW_LAUNCH_TW(0, 256); else if (stage == 1) RTW_LAUNCH_TW(1, 1024); else if (stage == 2) RTW_LAUNCH_TW(2, 1024); else RTW_LAUNCH_TW(3, 1024);
-#undef RTW_LAUNCH_TW
-            }
-            if (r == 1 && tune.wave_tail && tune.wave_stage > 0) {
-                // after shade(0) / trace(0): ONE kernel finishes the frame (shade(1), trace(1), ... ) for the paths of trace list 0
-                const long long paths = items_of(1);
-                constexpr int NT = 1024;
-                RtwRenderParams pt = p;
-                long long B = (paths + (long long)tune.wave_blocks * (NT / 64) - 1) / ((long long)tune.wave_blocks * (NT / 64));
-                if (B < 1) B = 1;
-                if (B > 32) B = 32;
-                pt.wave_paths = (int)B;
-                long long blocks = (paths + B * (NT / 64) - 1) / (B * (NT / 64));
+    auto items_of = [&](int round) {
+        if (round <= 1) return owners;      // the queue is round 0's trace list = round 1's input
+        const long long items = tune.round_hint[round - 1] >= 0 ? (long long)tune.round_hint[round - 1] + tune.round_hint[round - 1] / 4 + 256 : owners;
+        return items > owners ? owners : items;
+    };
+    constexpr int NTV = 128;                // wave-per-ray trace launches: 128-thread blocks (measured a little faster than 256: fewer waves coupled to one block)
+    const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
+    const long long trace_cap = (long long)tune.cu_count * (1024 / NTV) * 8;
+    for (int r = 1; r < p.max_bounce; r++) {
+        if (!tune.skip_trace) {
+            const long long rays = items_of(r);
+            if (p.lead_shapes > 0) {        // leading analytic shapes: the records are half done, most rays need no trace (see trace_wave_lead_kernel)
+                int shift = 0;              // measured on SetupScene: 4 entries per wave at a time 1.64 ms, 16: 1.67, 64: 1.84, 1: 1.80 (flagged rays cluster: small chunks spread them over the waves)
+                while (shift < 2 && (rays >> (shift + 1)) >= 16384) shift++;
+                long long blocks = ((rays >> shift) + NTV / 64) / (NTV / 64);
                 if (blocks < 1) blocks = 1;
-                if (blocks > tune.wave_blocks) blocks = tune.wave_blocks;
-                const size_t dyn = (size_t)(NT / 64) * RTW_WAVE_LDS_WORDS * 4 + tune.wave_stage_bytes;
-#define RTW_LAUNCH_TAIL(ST)                                                                                                              \
-                do {                                                                                                                     \
-                    if (stats) { (void)hipFuncSetAttribute((const void*)pathwave_kernel<true, ST, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                        hipLaunchKernelGGL((pathwave_kernel<true, ST, NT, true>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, pt); } \
-                    else { (void)hipFuncSetAttribute((const void*)pathwave_kernel<false, ST, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                        hipLaunchKernelGGL((pathwave_kernel<false, ST, NT, true>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, pt); } \
-                } while (0)
-                if (tune.wave_stage == 1) RTW_LAUNCH_TAIL(1); else if (tune.wave_stage == 2) RTW_LAUNCH_TAIL(2); else RTW_LAUNCH_TAIL(3);
-#undef RTW_LAUNCH_TAIL
-                break;
-            }
-            long long sb = (items_of(r) + 255) / 256;
-            if (sb < 1) sb = 1;
-            if (sb > 262144) sb = 262144;
-            const int last = (p.resolve_inline && r == p.max_bounce - 1) ? 1 : 0;     // no resolve launch follows: this one closes the pass
-            if (tune.has_analytic) {
-                if (stats) hipLaunchKernelGGL((shade_kernel<true, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
-                else hipLaunchKernelGGL((shade_kernel<false, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
+                if (blocks > trace_cap) blocks = trace_cap;
+                if (stats) hipLaunchKernelGGL((trace_wave_lead_kernel<true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
+                else hipLaunchKernelGGL((trace_wave_lead_kernel<false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1, shift);
             } else {
-                if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
-                else hipLaunchKernelGGL((shade_kernel<false, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r, last);
+                long long blocks = (rays + NTV / 64 - 1) / (NTV / 64);
+                if (blocks < 1) blocks = 1;
+                if (blocks > trace_cap) blocks = trace_cap;
+                if (tune.has_analytic) {    // analytic shapes somewhere after a mesh: the general wave-per-ray query
+                    if (stats) hipLaunchKernelGGL((trace_wave_kernel<true, NTV, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
+                    else hipLaunchKernelGGL((trace_wave_kernel<false, NTV, true>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
+                } else {
+                    if (stats) hipLaunchKernelGGL((trace_wave_kernel<true, NTV, false>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
+                    else hipLaunchKernelGGL((trace_wave_kernel<false, NTV, false>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, pb, p, r - 1);
+                }
             }
         }
-    } else if (p.wavefront == 2) {
-        // one wave per p.wave_paths queued paths; blocks past the real queue leave at once
-        long long waves = ((long long)owners + p.wave_paths - 1) / p.wave_paths;
-        const int stage = tune.wave_stage;
-        if (stage > 0) {
-            constexpr int NT = 1024;        // one block per CU: its 16 waves share the staged arrays
-            long long blocks = (waves + NT / 64 - 1) / (NT / 64);
-            if (blocks < 1) blocks = 1;
-            if (blocks > tune.wave_blocks) blocks = tune.wave_blocks;
-            const size_t dyn = (size_t)(NT / 64) * RTW_WAVE_LDS_WORDS * 4 + tune.wave_stage_bytes;
-#define RTW_LAUNCH_PW(ST)                                                                                                                \
-            do {                                                                                                                         \
-                if (stats) { (void)hipFuncSetAttribute((const void*)pathwave_kernel<true, ST, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                    hipLaunchKernelGGL((pathwave_kernel<true, ST, NT, false>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }     \
-                else { (void)hipFuncSetAttribute((const void*)pathwave_kernel<false, ST, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-                    hipLaunchKernelGGL((pathwave_kernel<false, ST, NT, false>), dim3((unsigned)blocks), dim3(NT), dyn, stream, sc, pb, p); }    \
-            } while (0)
-            if (stage == 1) RTW_LAUNCH_PW(1); else if (stage == 2) RTW_LAUNCH_PW(2); else RTW_LAUNCH_PW(3);
-#undef RTW_LAUNCH_PW
+        long long sb = (items_of(r) + 255) / 256;
+        if (sb < 1) sb = 1;
+        if (sb > 262144) sb = 262144;
+        if (tune.has_analytic) {
+            if (stats) hipLaunchKernelGGL((shade_kernel<true, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+            else hipLaunchKernelGGL((shade_kernel<false, true>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
         } else {
-            long long blocks = (waves + 3) / 4;
-            if (blocks < 1) blocks = 1;
-            if (blocks > 262144) blocks = 262144;
-            const size_t dyn = 4 * RTW_WAVE_LDS_WORDS * 4;
-            if (stats) hipLaunchKernelGGL((pathwave_kernel<true, 0, 256, false>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
-            else hipLaunchKernelGGL((pathwave_kernel<false, 0, 256, false>), dim3((unsigned)blocks), dim3(256), dyn, stream, sc, pb, p);
+            if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
+            else hipLaunchKernelGGL((shade_kernel<false, false>), dim3((unsigned)sb), dim3(256), 0, stream, sc, pb, p, r);
         }
-    } else if (p.wavefront) {
-        // shade(0), then trace(r) / shade(r + 1): a path queued with a hit record ends at the latest in shade(max_bounce - 1),
-        // one whose camera ray still has to be traced in shade(max_bounce)
-        auto size_for = [&](int round, int lanes_per_item) {
-            long long items = round == 0 ? owners : (tune.round_hint[round - 1] >= 0 ? (long long)tune.round_hint[round - 1] + tune.round_hint[round - 1] / 4 + 256 : owners);
-            if (items > owners) items = owners;
-            long long blocks = (items * lanes_per_item + 255) / 256;
-            if (blocks < 1) blocks = 1;
-            if (blocks > 262144) blocks = 262144;
-            return (int)blocks;
-        };
-        for (int r = 0; r <= p.max_bounce; r++) {
-            if (r > 0) {
-                const int tb = size_for(r, 16);
-                if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
-                else hipLaunchKernelGGL(trace_kernel<false>, dim3(tb), dim3(256), 0, stream, sc, pb, p, r - 1);
-            }
-            const int sb = size_for(r, 1);
-            if (stats) hipLaunchKernelGGL((shade_kernel<true, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r, 0);      // (scenes with analytic shapes never take this pipeline)
-            else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(sb), dim3(256), 0, stream, sc, pb, p, r, 0);
-        }
-    } else if (tune.path_lanes == 16 && tune.path_variant == 1 && tune.lds_wide_count > 0) {
-        constexpr int NT = 256;         // experiment: no register cap (2 waves/SIMD), staged tree per 4 waves
-        const int blocks = (owners + NT / 16 - 1) / (NT / 16);
-        const size_t dyn = (size_t)tune.lds_wide_count * 448;
-        if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT, 16, 2>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
-        else hipLaunchKernelGGL((path_kernel<false, true, NT, 16, 2>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
-    } else if (tune.path_lanes == 16 && tune.path_variant == 2) {
-        constexpr int NT = 256;         // experiment: tree through L2, 3 waves/SIMD
-        const int blocks = (owners + NT / 16 - 1) / (NT / 16);
-        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 16, 3>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-        else hipLaunchKernelGGL((path_kernel<false, false, NT, 16, 3>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-    } else if (tune.path_lanes == 16 && tune.path_variant == 3) {
-        constexpr int NT = 256;         // experiment: tree through L2, 2 waves/SIMD, no spills
-        const int blocks = (owners + NT / 16 - 1) / (NT / 16);
-        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 16, 2>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-        else hipLaunchKernelGGL((path_kernel<false, false, NT, 16, 2>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-    } else if (tune.path_lanes == 16) {
-        if (tune.lds_wide_count > 0) {
-            constexpr int NT = 512;     // two blocks per CU share the staged tree between 16 waves
-            int blocks = (owners + NT / 16 - 1) / (NT / 16);
-            const size_t dyn = (size_t)tune.lds_wide_count * 448;
-            if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT, 16>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
-            else hipLaunchKernelGGL((path_kernel<false, true, NT, 16>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, tune.lds_wide_count);
-        } else {
-            constexpr int NT = 256;
-            const int blocks = (owners + NT / 16 - 1) / (NT / 16);
-            if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 16>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-            else hipLaunchKernelGGL((path_kernel<false, false, NT, 16>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-        }
-    } else if (tune.path_lanes == 1) {
-        constexpr int NT = 256;
-        const int blocks = (owners + NT - 1) / NT;
-        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 1>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-        else hipLaunchKernelGGL((path_kernel<false, false, NT, 1>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-    } else if (lds_quad_count > 0) {
-        // small mesh: every quad of shape 0 in LDS, big blocks so that the staged tree is shared by 16 waves
-        constexpr int NT = RTW_PATH_BLOCK_LDS;
-        const int blocks = (owners + NT / 4 - 1) / (NT / 4);
-        const size_t dyn = (size_t)lds_quad_count * 128;
-        if (stats) hipLaunchKernelGGL((path_kernel<true, true, NT, 4>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
-        else hipLaunchKernelGGL((path_kernel<false, true, NT, 4>), dim3(blocks), dim3(NT), dyn, stream, sc, pb, p, lds_quad_count);
-    } else {
-        constexpr int NT = 256;
-        const int blocks = (owners + NT / 4 - 1) / (NT / 4);
-        if (stats) hipLaunchKernelGGL((path_kernel<true, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
-        else hipLaunchKernelGGL((path_kernel<false, false, NT, 4>), dim3(blocks), dim3(NT), 0, stream, sc, pb, p, 0);
     }
     if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
-    if (!p.resolve_inline) hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
+    hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks), dim3(block), 0, stream, sc, (float4*)accum, (uint32_t*)argb, pb, p);
     if (forked && tune.do_join) {           // the pass (or the run of passes) is complete when both streams are
         (void)hipStreamWaitEvent(stream, tune.join_event, 0);
         if (tune.aux_unjoined) *tune.aux_unjoined = false;
@@ -2341,13 +1488,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                     if (tune.has_analytic) { if (stats) RTW_LAUNCH_GT(true, true, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, true, NT_, CAP_, STG, BLOCKS, DYN); } \
                     else { if (stats) RTW_LAUNCH_GT(true, false, NT_, CAP_, STG, BLOCKS, DYN); else RTW_LAUNCH_GT(false, false, NT_, CAP_, STG, BLOCKS, DYN); } \
                 } while (0)
-                if (!tune.has_analytic && tune.wide_ok && trace_hint >= 0 && trace_hint < tune.wide_below && trace_hint >= tune.wave_below) {
-                    // a medium list: sixteen lanes per ray on the 16-wide tree
-                    long long blocks = ((long long)trace_hint + trace_hint / 4 + 256 + 15) / 16;
-                    if (blocks > 262144) blocks = 262144;
-                    if (stats) hipLaunchKernelGGL(gtrace_wide_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, sc, gb, r - 1);
-                    else hipLaunchKernelGGL(gtrace_wide_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, sc, gb, r - 1);
-                } else if (!tune.carry && trace_hint >= 0 && trace_hint < tune.wave_below) {
+                if (!tune.carry && trace_hint >= 0 && trace_hint < tune.wave_below) {
                     // a short list: a wave per ray (128-thread blocks, a wave takes rays in turn)
                     constexpr int NTV = 128;
                     long long blocks = ((long long)trace_hint + trace_hint / 4 + 64 + NTV / 64 - 1) / (NTV / 64);
@@ -2362,7 +1503,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
                         else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
                     }
-                } else if (tune.single_mesh && tune.persist) {
+                } else if (tune.single_mesh && tune.staged_shape == 0 && tune.staged_top > 0) {
                     // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
 #define RTW_LAUNCH_GP(NT_, CAP_, STG, BLOCKS, DYN)                                                                                               \
                     do {                                                                                                                        \
@@ -2371,17 +1512,12 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
                             hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget); } \
                     } while (0)
-                    if (tune.staged_shape == 0 && tune.staged_top > 0) {
+                    {
                         unsigned sbl = (tb + 3) / 4;
                         if (sbl > (unsigned)tune.cu_count) sbl = (unsigned)tune.cu_count;
                         const size_t dyn = (size_t)RTW_GT_CAP_STAGED * 1024 * 4 + (size_t)tune.staged_top * 32;
                         if (tune.staged_all) RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 2, sbl, dyn);
                         else RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 1, sbl, dyn);
-                    } else {
-                        unsigned bl = tb;
-                        if (bl > (unsigned)tune.cu_count * 8u) bl = (unsigned)tune.cu_count * 8u;
-                        const size_t dyn = (size_t)RTW_GT_CAP * 256 * 4;
-                        RTW_LAUNCH_GP(256, RTW_GT_CAP, 0, bl, dyn);
                     }
 #undef RTW_LAUNCH_GP
                     if (tune.visit_budget < INT32_MAX) {        // the rays that ran out of budget: a wave each

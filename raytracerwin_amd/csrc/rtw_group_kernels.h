@@ -99,7 +99,7 @@ template <bool STATS, bool AN>
 __device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__ sc, const RtwRenderParams& p, const GroupBufs& gb, uint32_t slot,
                                                  Ray& ray, PathRng& rng, int& depth, int& nlev, float4 r0, float4 r1, float4 r2, f3& L, Counters& ct)
 {
-    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
+    const TravCtx tc = make_trav();
     if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
     LevelStore lv; lv.ws = gb.levels; lv.stride = (size_t)gb.capacity; lv.tid = (size_t)slot; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
     L = mk(0, 0, 0);
@@ -956,60 +956,10 @@ __global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __re
             const float4 h0 = cld4(gb.hit, q * 2), h1 = cld4(gb.hit, q * 2 + 1);
             pos = mk(h0.x, h0.y, h0.z); seg = h0.w; hs = __float_as_int(h1.x); slot = __float_as_int(h1.y);
         }
-        wave_find_intersection<STATS, 0, AN>(sc, AN ? lead : 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
+        wave_find_intersection<STATS, AN>(sc, AN ? lead : 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
         if (lane_id() == 0) {
             gb.hit[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             gb.hit[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), __int_as_float(-1), __int_as_float(-1));
-        }
-    }
-    if (STATS) flush_counters(sc, ct);
-}
-
-// The same round for a MEDIUM list: sixteen lanes per ray over the 16-wide collapse of the tree (wide_walk16, rtw_device.hip): a ray's
-// chain of dependent steps is a handful of 16-box nodes instead of ~100 binary ones, at about the ray-per-lane kernel's instruction
-// count per ray.  Mesh-only scenes.
-template <bool STATS>
-__global__ __launch_bounds__(256) void gtrace_wide_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round)
-{
-    __shared__ uint32_t trav_words[(RTW_WIDE_STACK + RTW_WIDE_CAND) * 16];
-    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
-    if (blockIdx.x * 16u >= n) return;
-    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
-    const TravCtx tc = make_trav16(trav_words, 256, nullptr);
-    const uint32_t ngroups = gridDim.x * 16u;
-    Counters ct = { 0, 0, 0, 0, 0, 0 };
-    const bool prune = sc->prune != 0;
-    for (uint32_t k = blockIdx.x * 16u + (threadIdx.x >> 4); k < n; k += ngroups) {
-        const uint32_t q = src[k];
-        const float4 s0 = gb.state[(size_t)q * 3], s1 = gb.state[(size_t)q * 3 + 1];
-        Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
-        int hit_shape = -1, hit_slot = -1;
-        f3 hit_pos = mk(0, 0, 0);
-        float seg = ray.dist;
-        if (STATS && tc.count) ct.rays++;
-        const bool tame = ray_is_tame(ray);
-        for (int s = 0; s < sc->n_shapes; s++) {
-            const RtwShapeDev& sh = sc->shapes[s];
-            float t0, t1;
-            if (STATS && tc.count) ct.boxes++;
-            if (!slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1)) continue;
-            float cur = seg; f3 pos = mk(0, 0, 0); int slot = -1;
-            bool any;
-            Counters walk = { 0, 0, 0, 0, 0, 0 };
-            if (sh.n_wides > 0) {
-                if (tame) any = wide_walk16<STATS, false, false>(sh, tc, ray, prune, cur, pos, slot, walk);
-                else any = wide_walk16<STATS, false, true>(sh, tc, ray, false, cur, pos, slot, walk);
-                if (STATS) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
-            } else {
-                if (tame) any = tree_walk<true, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, prune, cur, pos, slot, walk);
-                else any = tree_walk<false, STATS>(sc, sh.nodes, sh.tris, sh.n_nodes, sh.n_tris, ray, false, cur, pos, slot, walk);
-                if (STATS && tc.count) { ct.boxes += walk.boxes; ct.tris += walk.tris; }
-            }
-            if (any) { seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos; }
-        }
-        if (tc.lane4 == 0) {
-            gb.hit[(size_t)q * 2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, seg);
-            gb.hit[(size_t)q * 2 + 1] = make_float4(__int_as_float(hit_shape), __int_as_float(hit_slot), __int_as_float(-1), __int_as_float(-1));
         }
     }
     if (STATS) flush_counters(sc, ct);

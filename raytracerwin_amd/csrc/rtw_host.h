@@ -34,10 +34,6 @@ struct HostMesh {
     std::vector<RtwNode> nodes;
     std::vector<RtwTri> tris;          // leaf order
     std::vector<RtwShade> shade;       // leaf order
-    std::vector<RtwQuad> quads;        // 4-wide collapse of `nodes`, BFS order
-    int quad_depth = 0;
-    std::vector<RtwWide> wides;        // 16-wide collapse, BFS order
-    int wide_depth = 0;
     int max_depth = 0;
     std::vector<RtwPNode> tnodes;      // the tree with explicit links, upper levels first (RtwShapeDev::tnodes)
     int tnodes_top = 0;
@@ -56,8 +52,6 @@ std::string finish_arrays(HostMesh& m, const float* bounds6);
 void triangle_plane(const float p0[3], const float p1[3], const float p2[3], float n[3], float* d1);
 // KdNode::Build restated (Src/KdTree.cpp:37-126) + flatten to preorder/skip-link form.
 void build_tree(HostMesh& m);
-// 4-wide collapse of m.nodes (slot order = preorder), numbered breadth-first.
-void build_quads(HostMesh& m);
 // The tree with explicit links, the at most `top_budget` records of its upper levels first (needs build_tree()).
 void build_tnodes(HostMesh& m, int top_budget);
 // Flat hierarchy: leaf boxes in preorder and the unions of every 16 / 256 consecutive leaves (needs build_tree()).

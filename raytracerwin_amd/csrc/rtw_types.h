@@ -37,30 +37,6 @@ struct RtwShade {           // 4 x 16 B
 };
 static_assert(sizeof(RtwShade) == 64, "RtwShade");
 
-// 4-wide collapse of the same binary tree (slots keep the binary tree's left-to-right order, so a
-// depth-first walk meets the leaves in exactly the reference's order).  Slot boxes are the binary
-// nodes' own boxes; an empty slot has an inverted box that no ray can hit.
-struct RtwQuad {            // 8 x 16 B
-    float min_x[4], min_y[4], min_z[4];
-    float max_x[4], max_y[4], max_z[4];
-    int32_t child[4];       // >= 0: quad index; < 0 and != RTW_QUAD_EMPTY: leaf slot = -1 - child; RTW_QUAD_EMPTY: unused
-    int32_t pad[4];
-};
-static_assert(sizeof(RtwQuad) == 128, "RtwQuad");
-#define RTW_QUAD_EMPTY ((int32_t)0x80000000)
-#define RTW_QUAD_STACK 16   // deepest quad tree the LDS trail holds
-#define RTW_CAND_CAP 24     // candidate leaves gathered before their triangle tests run
-
-// 16-wide collapse of the same tree for the 16-lanes-per-ray walk: slot k of a node is tested by lane k.
-struct RtwWide {            // 7 x 64 B
-    float min_x[16], min_y[16], min_z[16];
-    float max_x[16], max_y[16], max_z[16];
-    int32_t child[16];      // same encoding as RtwQuad::child
-};
-static_assert(sizeof(RtwWide) == 448, "RtwWide");
-#define RTW_WIDE_STACK 8    // deepest 16-wide tree the trail holds
-#define RTW_WIDE_CAND 32    // candidate leaves gathered before their triangle tests run (two rounds of 16)
-
 struct RtwTexture {         // 16 B
     uint32_t offset;        // first texel in the atlas
     int32_t width, height;
@@ -85,9 +61,6 @@ struct RtwShapeDev {
     const RtwTri* tris;
     const RtwShade* shade;
     const uint32_t* texels;
-    const RtwQuad* quads;           // BFS order; null / n_quads == 0 -> binary walk only
-    const RtwWide* wides;           // BFS order; null / n_wides == 0 -> no 16-lane walk
-    int32_t n_wides, wide_depth;
     // flat hierarchy over the leaves in preorder (16 consecutive entries of a level share one entry of the next):
     // level 0 = the leaves' own boxes, 1 = groups of 16 leaves, 2 = groups of 256.  Entry i of a level is the 24 bytes
     // flat[l][6 i ..]: (min x, max x), (min y, max y), (min z, max z) -- one pair per axis, so that (pair - origin) * reciprocal
@@ -102,7 +75,6 @@ struct RtwShapeDev {
     // packed multiply per axis (v_pk_add_f32 / v_pk_mul_f32: component-wise the reference's float operations).
     const struct RtwPNode* tnodes;
     float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
-    int32_t n_quads, quad_depth;
     int32_t n_nodes, n_tris;
     int32_t n_textures;             // size of the reference's Textures vector (= triangle count when an MTL exists)
     int32_t has_material;
@@ -121,7 +93,7 @@ struct RtwShapeDev {
 struct RtwSceneDev {
     int32_t n_shapes;
     int32_t prune;
-    int32_t traversal;              // 1: 4-wide walk (default), 0: binary preorder walk (reference visit counts)
+    int32_t traversal;              // 1 (default): bins, flat hierarchy and link tree may be used; 0: binary preorder walk only (reference visit counts)
     int32_t debug_table_mask;       // timing experiments only: nonzero -> unit-table index &= mask (changes the image)
     const float* unit_table;        // 3 floats per entry
     const float* gamma_thr;         // 256
@@ -136,27 +108,15 @@ struct RtwRenderParams {
     int32_t task_rows, rank, world; // world <= 1: contiguous range
     int32_t max_bounce, preview, pass_index, sub_samples;
     uint32_t seed;
-    int32_t packets;                // 1: the primary kernel does the camera rays' scene query as packet walks
-    int32_t wavefront;              // 1: one shade + one trace launch per bounce instead of the all-in-one path kernel
     // tiled work mapping (tile_w != 0): wave w of the launch renders the tile_w x tile_h pixel tile number w of its rows,
     // aligned to the screen's bin grid; `bins` then holds, per shape, the leaves whose box can be met by a camera ray of each bin
     int32_t tile_w, tile_h, tile_shift, tiles_per_row;
     int32_t row0, nrows;            // contiguous range: first screen row and number of rows; task partition: number of virtual rows
-    int32_t wave_paths;             // paths a wave of pathwave_kernel owns at a time (1..64)
-    int32_t pad_params;
-    int32_t direct_slots;           // bins + wave pipeline: the primary kernel shades the camera rays' hits itself; a path's slot in the
-                                    // dense arrays is work item * sub_samples + sub-sample (no queue), pb.queue is round 0's trace list
-    int32_t lead_shapes;            // bins + wave pipeline with direct slots: the scene's first lead_shapes shapes are spheres / planes / capsules;
+    int32_t lead_shapes;            // the scene's first lead_shapes shapes are spheres / planes / capsules / triangles;
                                     // the lane that sets up a path's next segment (shade_hit_step) tests them there, one ray per lane, and
                                     // leaves the partial scene query in the path's hit record; the wave-per-ray trace continues from it
-    int32_t self_clean;             // resolve_kernel files the counters at word 64.. and zeroes them for the next pass
     int32_t n_jobs;                 // entries of tile_order
-    int32_t resolve_inline;         // bins + wave pipeline, ONE sample per pixel: the lane that ends a path accumulates and resolves its pixel
-                                    // there and then (no pending list, no resolve launch; the pass's last shade launch does the end-of-pass
-                                    // bookkeeping); with several samples a pixel waits for all of them and resolve_kernel sums them in order
-    int32_t pad_resolve;
     const struct RtwBinsDev* bins;  // [n_shapes] or null
-    int32_t* pass_ptr;              // not null: the pass index lives on the device (replayed launch graphs); resolve_kernel adds 1 to it
     const uint32_t* tile_order;     // full-frame launches: the order in which the primary kernel takes the tiles (null = as numbered)
     const float* cam_dx;            // tiled mapping: dx of every pixel column / dy of every pixel row (Src/RayTracerProgram.cpp:141-142),
     const float* cam_dy;            // computed once on the host with the same float operations

@@ -7,12 +7,9 @@
 //                        list -- wave-uniform index, records through scalar loads, nothing pointer-chased -- and each
 //                        lane gives its own ray the reference's box test and triangle test, in preorder, with its
 //                        own shrinking segment.  Misses are finished here, hits are queued with their hit record.
-//   pathwave_kernel      a wave owns `wave_paths` queued paths, one per lane, and carries them to their end: the
-//                        shading step runs lane-parallel (one path per lane), every secondary segment is then traced
-//                        by the WHOLE wave, one ray at a time: 64 lanes test 64 boxes of the flat hierarchy per step
-//                        (no stack, wave-uniform control flow, no divergence), candidate leaves come out in preorder
-//                        and are triangle-tested 64 at a time with the reference's shrinking segment.  No relaunch
-//                        per bounce, no inter-wave traffic.
+//   trace_wave_kernel    every secondary segment is traced by a WHOLE wave, one ray at a time: 64 lanes test 64 boxes of the flat
+//                        hierarchy per step (no stack, wave-uniform control flow, no divergence), candidate leaves come out in preorder
+//                        and are triangle-tested 64 at a time with the reference's shrinking segment.
 //
 // Why the results are the reference's bits: KdNode::TestRayIntersection (Src/KdTree.cpp:128-195) tests exactly the
 // leaves whose own box the ray's line meets, in preorder, each with the segment left by the previous accepted hit.
@@ -23,9 +20,6 @@
 #define RTW_WAVE_LDS_WORDS 256      // per wave: 64 level-2 hits, 64 level-1 hits, 128 candidate leaves
 #ifndef RTW_TRACEWAVE_MINW
 #define RTW_TRACEWAVE_MINW 1     // (8 = 64 VGPRs with a small spill measured slower than the natural 75 VGPRs / 6 waves per SIMD)
-#endif
-#ifndef RTW_PATHWAVE_MINW
-#define RTW_PATHWAVE_MINW 4
 #endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
@@ -47,30 +41,20 @@ struct FlatRay { f3 o; float ix, iy, iz, eps_t; bool skx, sky, skz; };   // sk*:
 
 // reference box test of a tame ray (RRay::TestIntersectionWithAabb, Src/RRay.cpp:89-136) on entry idx of a flat
 // level, plus the conservative segment clip when `prune`
-// LDSB: the level's arrays were staged in LDS by the block (same layout).  EXACT: the ray is not "tame" (a direction
-// component below FLT_EPSILON, NaN, ...): the reference's test as written (skipped axes, Math::Min/Max), no clip.
+// EXACT: the ray is not "tame" (a direction component below FLT_EPSILON, NaN, ...): the reference's test as written (skipped axes,
+// Math::Min/Max), no clip.
 typedef float rtw_v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const rtw_v2f rtw_g_v2;
-typedef __attribute__((address_space(3))) const rtw_v2f rtw_l_v2;
-template <bool LDSB, bool EXACT>
-__device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pad, int idx, const FlatRay& fr, bool prune, float far_t)
+template <bool EXACT>
+__device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int idx, const FlatRay& fr, bool prune, float far_t)
 {
-    (void)pad;
     // the entry's three (min, max) pairs; (pair - origin) * reciprocal is one packed subtract + one packed multiply per axis,
     // component-wise the reference's float operations
     rtw_v2f bx, by, bz;
-    if (LDSB) { const rtw_l_v2* e = (rtw_l_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
-    else { const rtw_g_v2* e = (rtw_g_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
-#ifdef RTW_PACKED_BOX
-    const rtw_v2f ox = { fr.o.x, fr.o.x }, oy = { fr.o.y, fr.o.y }, oz = { fr.o.z, fr.o.z };
-    const rtw_v2f vx = { fr.ix, fr.ix }, vy = { fr.iy, fr.iy }, vz = { fr.iz, fr.iz };
-    const rtw_v2f tx = (bx - ox) * vx, ty = (by - oy) * vy, tz = (bz - oz) * vz;
-    const float x1 = tx.x, x2 = tx.y, y1 = ty.x, y2 = ty.y, z1 = tz.x, z2 = tz.y;
-#else
+    { const rtw_g_v2* e = (rtw_g_v2*)b + (size_t)idx * 3; bx = e[0]; by = e[1]; bz = e[2]; }
     const float x1 = (bx.x - fr.o.x) * fr.ix, x2 = (bx.y - fr.o.x) * fr.ix;
     const float y1 = (by.x - fr.o.y) * fr.iy, y2 = (by.y - fr.o.y) * fr.iy;
     const float z1 = (bz.x - fr.o.z) * fr.iz, z2 = (bz.y - fr.o.z) * fr.iz;
-#endif
     if (EXACT) {
         float tmin = -FLT_MAX, tmax = FLT_MAX;
         if (!fr.skx) { tmin = ref_max(tmin, ref_min(x1, x2)); tmax = ref_min(tmax, ref_max(x1, x2)); }
@@ -85,8 +69,7 @@ __device__ __forceinline__ bool flat_box_hit(const float* __restrict__ b, int pa
     return h;
 }
 
-// What a block of pathwave_kernel staged in LDS for shape 0 (null = read through L2).  STAGE 0: nothing, 1: levels 2 and 1,
-// 2: all three levels, 3: the levels and the triangle records.
+// a shape's flat hierarchy, copied out of the scene descriptor once (no reloads in the walk)
 struct FlatSrc {
     const float* lvl[3]; const float4* tris;
     int n[3], pad[3];           // entries and array stride of each level (copied out of the shape once: no reloads in the walk)
@@ -104,7 +87,7 @@ __device__ __forceinline__ FlatSrc flat_src_of(const RtwShapeDev& sh)
 // triangle tests of the n candidate leaves in lds_c[0..n) (ascending = preorder), 64 at a time.  A test must see
 // the segment left by every earlier accepted hit, so after an accept the later lanes are tested again with the
 // shortened segment (the reference tests them one after another).
-template <bool STATS, bool LDST>
+template <bool STATS>
 __device__ __forceinline__ void wave_triangles(const float4* __restrict__ tr4, const uint32_t* __restrict__ lds_c, int n, const Ray& r,
                                                float& cur_dist, f3& hit_pos, int& hit_slot, bool& any, Counters& ct)
 {
@@ -113,8 +96,7 @@ __device__ __forceinline__ void wave_triangles(const float4* __restrict__ tr4, c
         const bool mine = j + lane < n;
         const int leaf = mine ? (int)lldu(lds_c, j + lane) : 0;
         float4 a, b, c, d;
-        if (LDST) { a = lld4(tr4, 4 * leaf); b = lld4(tr4, 4 * leaf + 1); c = lld4(tr4, 4 * leaf + 2); d = lld4(tr4, 4 * leaf + 3); }
-        else { a = gld4(tr4, 4 * (size_t)leaf); b = gld4(tr4, 4 * (size_t)leaf + 1); c = gld4(tr4, 4 * (size_t)leaf + 2); d = gld4(tr4, 4 * (size_t)leaf + 3); }
+        a = gld4(tr4, 4 * (size_t)leaf); b = gld4(tr4, 4 * (size_t)leaf + 1); c = gld4(tr4, 4 * (size_t)leaf + 2); d = gld4(tr4, 4 * (size_t)leaf + 3);
         if (STATS) ct.tris += mine ? 1u : 0u;
         int settled = -1;
         for (;;) {
@@ -134,7 +116,7 @@ __device__ __forceinline__ void wave_triangles(const float4* __restrict__ tr4, c
 
 // KdTree::TestRayIntersection for ONE tame ray held identically by all 64 lanes.  Depth-first over the three flat
 // levels, four entries (64 children) per step, so the leaves come out in ascending slot order = preorder.
-template <bool STATS, int STAGE, bool EXACT>
+template <bool STATS, bool EXACT>
 __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __restrict__ lds, const Ray& r, const FlatRay& fr, bool prune,
                                                float& cur_dist, f3& hit_pos, int& hit_slot, Counters& ct)
 {
@@ -147,7 +129,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
         float far_t = cur_dist + (fr.eps_t + 1.0e-4f * cur_dist);
         const int i2 = t0 + lane;
         const bool v2 = i2 < n2;
-        const bool h2 = v2 && flat_box_hit<(STAGE >= 1), EXACT>(src.lvl[2], src.pad[2], i2, fr, prune, far_t);
+        const bool h2 = v2 && flat_box_hit<EXACT>(src.lvl[2], i2, fr, prune, far_t);
         if (STATS) ct.boxes += v2 ? 1u : 0u;
         const unsigned long long m2 = __ballot(h2);
         if (m2 == 0ull) continue;
@@ -159,7 +141,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
             const int g = g2 + lane;
             const int i1 = (g < c2 ? (int)lldu(l2, g >> 4) : 0) * 16 + (g & 15);
             const bool v1 = g < c2 && i1 < n1;
-            const bool h1 = v1 && flat_box_hit<(STAGE >= 1), EXACT>(src.lvl[1], src.pad[1], i1, fr, prune, far_t);
+            const bool h1 = v1 && flat_box_hit<EXACT>(src.lvl[1], i1, fr, prune, far_t);
             if (STATS) ct.boxes += v1 ? 1u : 0u;
             const unsigned long long m1 = __ballot(h1);
             if (m1 == 0ull) continue;
@@ -171,7 +153,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
                 const int gg = g1 + lane;
                 const int i0 = (gg < c1 ? (int)lldu(l1, gg >> 4) : 0) * 16 + (gg & 15);
                 const bool v0 = gg < c1 && i0 < n0;
-                const bool h0 = v0 && flat_box_hit<(STAGE >= 2), EXACT>(src.lvl[0], src.pad[0], i0, fr, prune, far_t);
+                const bool h0 = v0 && flat_box_hit<EXACT>(src.lvl[0], i0, fr, prune, far_t);
                 if (STATS) ct.boxes += v0 ? 1u : 0u;
                 const unsigned long long m0 = __ballot(h0);
                 if (m0 == 0ull) continue;
@@ -179,7 +161,7 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
                 ncand += __popcll(m0);
                 if (ncand > 64) {                   // the list holds 128: make room before the next 64
                     wave_lds_sync();
-                    wave_triangles<STATS, (STAGE >= 3)>(src.tris, lc, ncand, r, cur_dist, hit_pos, hit_slot, any, ct);
+                    wave_triangles<STATS>(src.tris, lc, ncand, r, cur_dist, hit_pos, hit_slot, any, ct);
                     wave_lds_sync();
                     ncand = 0;
                     far_t = cur_dist + (fr.eps_t + 1.0e-4f * cur_dist);
@@ -189,20 +171,19 @@ __device__ __forceinline__ bool wave_walk_flat(const FlatSrc& src, uint32_t* __r
     }
     if (ncand > 0) {
         wave_lds_sync();
-        wave_triangles<STATS, (STAGE >= 3)>(src.tris, lc, ncand, r, cur_dist, hit_pos, hit_slot, any, ct);
+        wave_triangles<STATS>(src.tris, lc, ncand, r, cur_dist, hit_pos, hit_slot, any, ct);
         wave_lds_sync();
     }
     return any;
 }
 
 // FindIntersectionWithScene (Src/RayTracerScene.cpp:99-125) of one ray held by the whole wave, without the shading
-// tail (only the record of the last shape that hit is read afterwards).  `shape0` describes shape 0 (its arrays staged
-// in LDS when STAGE > 0); later shapes are read from the scene.
+// tail (only the record of the last shape that hit is read afterwards).  `shape0` describes shape 0; later shapes are read from the scene.
 // The query covers shapes [first_shape, n_shapes) and continues from the caller's (hit_shape, hit_slot, hit_pos, seg): for a fresh
 // query that is (-1, -1, 0, ray.dist) with first_shape 0; with leading analytic shapes already tested by the shading lane
 // (RtwRenderParams::lead_shapes) it is that partial result.
 // AN = the scene may hold spheres / planes / capsules; mesh-only scenes run instantiations without that code (registers, occupancy).
-template <bool STATS, int STAGE, bool AN>
+template <bool STATS, bool AN>
 __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __restrict__ sc, int first_shape, int n_shapes, bool prune, const FlatSrc& shape0,
                                                        uint32_t* __restrict__ lds, const Ray& ray,
                                                        int& hit_shape, int& hit_slot, f3& hit_pos, float& seg, Counters& ct)
@@ -243,10 +224,9 @@ __device__ __forceinline__ void wave_find_intersection(const RtwSceneDev* __rest
             any = analytic_test(sc->shapes[s], ray, seg, pos, cur, slot);
         } else if (g.n[0] > 0) {
             if (tame) {
-                if (STAGE > 0 && s == 0) any = wave_walk_flat<STATS, STAGE, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
-                else any = wave_walk_flat<STATS, 0, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
+                any = wave_walk_flat<STATS, false>(g, lds, ray, fr, prune, cur, pos, slot, ct);
             } else {                // rare (a direction component below FLT_EPSILON, NaN, ...): same walk, the reference's test as written
-                any = wave_walk_flat<STATS, 0, true>(flat_src_of(sc->shapes[s]), lds, ray, fr, false, cur, pos, slot, ct);
+                any = wave_walk_flat<STATS, true>(g, lds, ray, fr, false, cur, pos, slot, ct);
             }
         } else {                    // a shape without a flat hierarchy: the reference's own walk, all lanes alike
             const RtwShapeDev& sh = sc->shapes[s];
@@ -283,7 +263,7 @@ __global__ __launch_bounds__(256) void primary_sky_kernel(const float* __restric
         if (!p.preview) acc_prev = accum[pixel];
         f3 csum = mk(0, 0, 0);
         for (int i = 0; i < p.sub_samples; i++) {
-            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)i);
+            PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)p.pass_index, (uint32_t)i);
             const Ray ray = camera_ray_xy(p, px, py, i, rng);
             const f3 si = p.max_bounce != 0 ? sky_color(ray.d.y) : mk(0, 0, 0);       // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
             csum = csum + si;
@@ -332,7 +312,7 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     const int pixel = live ? py * p.width + px : npix;
     // the accumulator entry is needed at the very end: ask for it now
     float4 acc_prev = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live && !p.preview && !(p.pad_params & 2)) acc_prev = accum[pixel];
+    if (live && !p.preview) acc_prev = accum[pixel];
     // the wave's bin: all its pixels lie in one tile of the screen's bin grid (tile rows never straddle a bin row)
     const unsigned long long live_mask = __ballot(live);
     int bin = 0;
@@ -353,13 +333,13 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
     bool hit_any = false;                                    // some sample of this pixel hit something: the pixel is resolved later
     for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
         if (only_sample >= 0 && i != only_sample) continue;
-        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)pass_of(p), (uint32_t)i);
+        PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)(live ? pixel : 0), (uint32_t)p.pass_index, (uint32_t)i);
         const Ray ray = camera_ray_xy(p, px, py, i, rng);
         if (STATS && live) ct.cams++;
         f3 si = mk(0, 0, 0);
         bool queue_it = false;
         float4 hr0 = make_float4(0.f, 0.f, 0.f, 0.f), hr1 = hr0;
-        if (p.max_bounce != 0 && ((!near_wave && !STATS) || (p.pad_params & 4))) {     // no leaf of any shape can be met from this tile: every sample sees the sky
+        if (p.max_bounce != 0 && !near_wave && !STATS) {     // no leaf of any shape can be met from this tile: every sample sees the sky
             if (live) si = sky_color(ray.d.y);
         } else if (p.max_bounce != 0) {                      // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
             // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
@@ -456,32 +436,28 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         }
         csum = csum + si;
         if (live && (near_wave || only_sample >= 0) && !queue_it) pb.rad[(size_t)wi * 4 + i] = make_float4(si.x, si.y, si.z, 0.0f);
-        if (queue_it && p.direct_slots) {                    // shade the hit here: the path's slot needs no queue position
+        if (queue_it) {                                      // shade the hit here: the path's slot needs no queue position
             hit_any = true;
-            if (shade_hit_step<STATS, AN>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, true, hr0, hr1, ct, thr))
+            if (shade_hit_step<STATS, AN>(sc, pb, p, slot_of_path(p, (uint32_t)wi, (uint32_t)i), (uint32_t)wi * 4u + (uint32_t)i, ray, rng, p.max_bounce, 0, hr0, hr1, ct))
                 queued |= 1u << i;                           // it goes on: its slot joins round 0's trace list below
-        } else if (queue_it) {                               // the hit record waits under the path id; the queue entry follows below
-            hit_any = true;
-            queued |= 1u << i;
-            pb.hitrec[((size_t)wi * 4 + i) * 2] = hr0; pb.hitrec[((size_t)wi * 4 + i) * 2 + 1] = hr1;
         }
     }
     // ONE atomic per wave for both lists (the two counters are one 64-bit word): the queue gets an entry per queued sample,
     // the pending list one per pixel with a queued sample
     // a tile split by sub-sample: every pixel is pending (listed once, by the wave of sub-sample 0)
     const bool pending = only_sample >= 0 ? live : hit_any;
-    const bool list_pixel = p.resolve_inline ? false : (only_sample >= 0 ? (live && only_sample == 0) : pending);      // resolve_inline: whoever ends the pixel's one path resolves it
+    const bool list_pixel = only_sample >= 0 ? (live && only_sample == 0) : pending;
     {
         const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
                                  m3 = __ballot((queued & 8u) != 0u), mp = __ballot(list_pixel);
-        if ((mp | m0 | m1 | m2 | m3) != 0ull && !(p.pad_params & 8)) {
+        if ((mp | m0 | m1 | m2 | m3) != 0ull) {
             const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
             unsigned long long base = 0ull;
             if (lane_id() == 0)
                 base = atomicAdd(reinterpret_cast<unsigned long long*>(pb.counters), (unsigned long long)(c0 + c1 + c2 + c3) | ((unsigned long long)__popcll(mp) << 32));
             const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
             const uint32_t pbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
-            const uint32_t e0 = p.direct_slots ? slot_of_path(p, (uint32_t)wi, 0u) : (uint32_t)wi * 4u;     // a slot (round 0's trace list) or a path id (the queue)
+            const uint32_t e0 = slot_of_path(p, (uint32_t)wi, 0u);
             const uint32_t es = 1u;
             if (queued & 1u) pb.queue[qb + (uint32_t)mbcnt(m0)] = e0;
             if (queued & 2u) pb.queue[qb + c0 + (uint32_t)mbcnt(m1)] = e0 + es;
@@ -497,66 +473,25 @@ __global__ __launch_bounds__(256) void primary_bins_kernel(const RtwSceneDev* __
         } else {                                             // AccumulatePixel::AddPixel + GetGammaSpacePixel (resolve_pixel, with the entry loaded above)
             const f3 sum = mk(acc_prev.x, acc_prev.y, acc_prev.z) + c;
             const int n = __float_as_int(acc_prev.w) + 1;
-            if (!(p.pad_params & 2)) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
-            if (p.pad_params & 1) argb[pixel] = __float_as_uint(sum.x);
-            else argb[pixel] = pack_pixel(thr, n == 1 ? sum : sum / (float)n);
+            accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
+            argb[pixel] = pack_pixel(thr, n == 1 ? sum : sum / (float)n);
         }
     }
   }
     if (STATS) flush_counters(sc, ct);
 }
 
-// ---- a wave carries `wave_paths` paths to their end ---------------------------------------------------------------
-// the block copies what STAGE says of shape 0 into LDS behind the waves' lists (whole block, ends with a barrier)
-template <int STAGE, int NT>
-__device__ __forceinline__ FlatSrc stage_shape0(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ wave_dyn)
-{
-    const RtwShapeDev& s0 = sc->shapes[0];
-    FlatSrc staged = flat_src_of(s0);
-    if (STAGE > 0) {
-        float* dst = reinterpret_cast<float*>(wave_dyn + (NT / 64) * RTW_WAVE_LDS_WORDS);
-        for (int l = 2; l >= (STAGE >= 2 ? 0 : 1); l--) {
-            const int words = 6 * staged.pad[l];        // a multiple of 4
-            const float4* src4 = reinterpret_cast<const float4*>(s0.flat[l]);
-            float4* dst4 = reinterpret_cast<float4*>(dst);
-            for (int i = (int)threadIdx.x; i < words / 4; i += NT) dst4[i] = gld4(src4, (size_t)i);
-            staged.lvl[l] = dst;
-            dst += words;
-        }
-        if (STAGE >= 3) {
-            const float4* src4 = reinterpret_cast<const float4*>(s0.tris);
-            float4* dst4 = reinterpret_cast<float4*>(dst);
-            for (int i = (int)threadIdx.x; i < s0.n_tris * 4; i += NT) dst4[i] = gld4(src4, (size_t)i);
-            staged.tris = dst4;
-        }
-        __syncthreads();
-    }
-    return staged;
-}
-
 // ---- one round of secondary segments: a wave per ray -----------------------------------------------------------------
-// The wavefront pipeline's trace step (see trace_kernel) with the whole wave on one ray: the ray comes in through scalar
-// loads, the walk is wave_walk_flat on the arrays the block staged in LDS.  Persistent blocks, one per CU when staged.
-// FINISH (the pass's last trace round, scenes without an Emissive material, no preview): what the last shade step would make of
-// the result needs neither the hit's shading inputs nor its material -- a path whose last segment misses gets the sky colour, one
-// whose last segment hits gets exactly 0 (RayTrace(.., 0) is black and nothing emits: Src/RayTracerScene.cpp:39,74-77; all material
-// colours are finite, so Att * 0 is 0) -- so lane 0 folds the path's levels right here, in the order shade_hit_step does, and the
-// pass has no last shade launch.  `closes_pass`: with resolve_inline this is then the pass's last launch.
-template <bool STATS, int STAGE, int NT, bool AN = false, bool FINISH = false>
-__global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round,
-                                                                                              int closes_pass = 0)
+// The ray comes in through scalar loads, the walk is wave_walk_flat; a wave takes rays in turn.
+template <bool STATS, int NT, bool AN>
+__global__ __launch_bounds__(NT) void trace_wave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round)
 {
-    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
-    __shared__ float thr[FINISH ? 256 : 1];
-    if (FINISH && p.resolve_inline) { for (int i = (int)threadIdx.x; i < 256; i += NT) thr[FINISH ? i : 0] = sc->gamma_thr[i]; __syncthreads(); }
-    const bool from_queue = p.direct_slots && round == 0;       // with direct slots the path queue IS round 0's trace list
+    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
+    const bool from_queue = round == 0;                  // the path queue IS round 0's trace list
     const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round];
-    // (whole block) no ray for this block's first wave; a FINISH launch that closes the pass always keeps block 0 (someone must file the counters)
-    const uint32_t busy_blocks = (n + (uint32_t)(NT / 64) - 1u) / (uint32_t)(NT / 64);
-    const uint32_t live_blocks = busy_blocks < gridDim.x ? (busy_blocks > 0u ? busy_blocks : 1u) : gridDim.x;
-    if ((uint32_t)blockIdx.x >= live_blocks) return;
+    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) >= n) return;       // (whole block) no ray for this block's first wave
     uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
-    const FlatSrc staged = stage_shape0<STAGE, NT>(sc, wave_dyn);
+    const FlatSrc shape0 = flat_src_of(sc->shapes[0]);
     const uint32_t* __restrict__ src = from_queue ? pb.queue : wf_list(pb, round & 1);
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
@@ -568,32 +503,13 @@ __global__ __launch_bounds__(NT, (NT == 256 ? RTW_TRACEWAVE_MINW : 1)) void trac
         const float4 s0 = cld4(pb.state, q * 3), s1 = cld4(pb.state, q * 3 + 1);
         Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
-        wave_find_intersection<STATS, STAGE, AN>(sc, 0, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
-        if (FINISH) {
-            if (lane_id() == 0) {
-                const int nlev = (int)(__float_as_uint(cld4(pb.state, q * 3 + 2).z) & 0xFFFFu);
-                LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
-                f3 L = hs < 0 ? sky_color(ray.d.y) : mk(0, 0, 0);
-                for (int kk = nlev - 1; kk >= 0; kk--) {
-                    const float4 a = lv.at(kk, 0);
-                    if (__float_as_int(a.w) == 0) {
-                        const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
-                        L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
-                    } else {
-                        L = mk(0, 0, 0) + L;
-                    }
-                }
-                const uint32_t pid = pid_of_slot(p, (uint32_t)q) & 0x7FFFFFFFu;
-                if (p.resolve_inline) resolve_pixel(thr, pb.accum, pb.argb, work_to_pixel(p, (int)(pid >> 2)), mk(0, 0, 0) + L, false);
-                else pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
-            }
-        } else if (lane_id() == 0) {
+        wave_find_intersection<STATS, AN>(sc, 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
+        if (lane_id() == 0) {
             pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
         }
     }
     if (STATS) flush_counters(sc, ct);
-    if (FINISH && closes_pass) pass_epilogue(pb, p, live_blocks);
 }
 
 // The trace step of a scene whose leading shapes are analytic (RtwRenderParams::lead_shapes > 0).  The lane that set a segment up
@@ -604,7 +520,7 @@ template <bool STATS, int NT>
 __global__ __launch_bounds__(NT) void trace_wave_lead_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p, int round, int chunk_shift)
 {
     HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS]
-    const bool from_queue = p.direct_slots && round == 0;
+    const bool from_queue = round == 0;
     const uint32_t n = from_queue ? pb.counters[0] : pb.counters[4 + round];
     const uint32_t chunk = 1u << chunk_shift;
     if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) * chunk >= n) return;
@@ -630,144 +546,10 @@ __global__ __launch_bounds__(NT) void trace_wave_lead_kernel(const RtwSceneDev* 
             Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
             const float4 h0 = cld4(pb.hitslot, q * 2), h1 = cld4(pb.hitslot, q * 2 + 1);
             f3 pos = mk(h0.x, h0.y, h0.z); float seg = h0.w; int hs = __float_as_int(h1.x), slot = __float_as_int(h1.y);
-            wave_find_intersection<STATS, 0, true>(sc, p.lead_shapes, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
+            wave_find_intersection<STATS, true>(sc, p.lead_shapes, n_shapes, prune, staged, lds, ray, hs, slot, pos, seg, ct);
             if (lane == 0u) {
                 pb.hitslot[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
                 pb.hitslot[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
-            }
-        }
-    }
-    if (STATS) flush_counters(sc, ct);
-}
-
-// RESUME: the paths are those of the first trace round's list (their state and the hit record of their second segment
-// are in the dense slot arrays): the kernel finishes what is left of the frame after the one big trace round, where the
-// later rounds' handful of rays would each pay a launch.
-template <bool STATS, int STAGE, int NT, bool RESUME>
-__global__ __launch_bounds__(NT, (NT == 256 ? RTW_PATHWAVE_MINW : 1)) void pathwave_kernel(const RtwSceneDev* __restrict__ sc, PipeBufs pb, RtwRenderParams p)
-{
-    HIP_DYNAMIC_SHARED(uint32_t, wave_dyn);              // [NT / 64 waves x RTW_WAVE_LDS_WORDS | staged arrays of shape 0]
-    const uint32_t B = (uint32_t)p.wave_paths;
-    const uint32_t nq = RESUME ? pb.counters[4] : pb.counters[0];
-    const uint32_t n = nq < pb.capacity ? nq : pb.capacity;
-    if ((uint32_t)blockIdx.x * (uint32_t)(NT / 64) * B >= n) return;     // (whole block) the grid is sized from the previous pass's queue length
-    uint32_t* lds = wave_dyn + (threadIdx.x >> 6) * RTW_WAVE_LDS_WORDS;
-    const FlatSrc staged = stage_shape0<STAGE, NT>(sc, wave_dyn);
-    const int n_shapes = sc->n_shapes;
-    const bool prune = sc->prune != 0;
-    const int lane = lane_id();
-    const uint32_t wave = (blockIdx.x * (uint32_t)NT + threadIdx.x) >> 6, nwaves = gridDim.x * (uint32_t)(NT / 64);
-    const int npix = p.width * p.height;
-    const uint32_t phase = table_phase(p.seed);
-    Counters ct = { 0, 0, 0, 0, 0, 0 };
-    TravCtx tc; tc.trail = nullptr; tc.cand = nullptr; tc.lds_quads = nullptr; tc.tid = 0; tc.nthr = 0; tc.lane4 = 0; tc.count = true;
-    for (uint32_t base = wave * B; base < n; base += nwaves * B) {
-        const uint32_t kq = base + (uint32_t)lane;
-        bool alive = (uint32_t)lane < B && kq < n;
-        const uint32_t q = RESUME ? (alive ? pb.tlist0[kq] : 0u) : kq;
-        if (RESUME && q >= pb.capacity) alive = false;
-        uint32_t pid = 0;
-        PathRng rng; rng.key = 0; rng.counter = 0; rng.table_base = 0; rng.table_reads = 0; rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
-        Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.dist = 0.0f;
-        int depth = 0, nlev = 0;
-        bool have_hit = false;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        if (alive && !RESUME) {
-            const uint32_t qe = pb.queue[q];
-            pid = qe & 0x7FFFFFFFu;
-            const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
-            const int pixel = work_to_pixel(p, wi);
-            rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass_of(p), (uint32_t)sub);
-            ray = camera_ray(p.width, p.height, pixel, sub, rng);
-            depth = p.max_bounce;
-            have_hit = !(qe >> 31);                      // else: an untame camera ray, its first segment is traced like any other
-            if (have_hit) { r0 = pb.hitrec[(size_t)pid * 2]; r1 = pb.hitrec[(size_t)pid * 2 + 1]; }     // the primary kernel files hit records under the path id
-        }
-        if (alive && RESUME) {                           // as shade_kernel picks a path up in round 1
-            pid = pb.queue[q] & 0x7FFFFFFFu;
-            const int wi = (int)(pid >> 2), sub = (int)(pid & 3u);
-            const int pixel = work_to_pixel(p, wi);
-            const float4 s0 = pb.state[(size_t)q * 3], s1 = pb.state[(size_t)q * 3 + 1], s2 = pb.state[(size_t)q * 3 + 2];
-            ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
-            rng.counter = __float_as_uint(s1.w); rng.key = __float_as_uint(s2.x); rng.table_reads = __float_as_uint(s2.y);
-            rng.table_base = (((uint64_t)pass_of(p) * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
-            nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu); depth = (int)(__float_as_uint(s2.z) >> 16);
-            have_hit = true;
-            r0 = pb.hitslot[(size_t)q * 2]; r1 = pb.hitslot[(size_t)q * 2 + 1];
-        }
-        LevelStore lv; lv.ws = pb.ws; lv.stride = (size_t)pb.capacity; lv.tid = (size_t)q; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
-        for (;;) {
-            bool need_trace = false;
-            if (alive) {
-                f3 L = mk(0, 0, 0);
-                bool done = false;
-                if (have_hit) {
-                    const int hs = __float_as_int(r1.x), slot = __float_as_int(r1.y);
-                    if (hs < 0) { L = sky_color(ray.d.y); done = true; }
-                    else {
-                        const RtwShapeDev& sh = sc->shapes[hs];
-                        Hit h; int tri_index;
-                        hit_finish<STATS>(sc, sh, tc, mk(r0.x, r0.y, r0.z), r0.w, slot, h, tri_index, ct);
-                        if (!sh.has_material) { L = mk(0, 0, 0); done = true; }
-                        else {
-                            Ray out = ray;
-                            if (p.preview) {
-                                const Bounce pv = material_eval<true>(sc, sh, ray, h, out, rng);
-                                L = mk(0, 0, 0) + pv.att * h.color; done = true;
-                            } else {
-                                const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
-                                if (rng.random() <= h.alpha) {
-                                    if (all_nonzero(b.att)) {
-                                        lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
-                                        lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
-                                        lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
-                                        nlev++;
-                                        ray = out;
-                                    } else { L = mk(0, 0, 0) + b.em; done = true; }
-                                } else {                 // transparent texel: same direction, remaining distance, no colour factor
-                                    lv.at(nlev, 0) = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(2));
-                                    nlev++;
-                                    const float rd = ray.dist - h.dist;
-                                    ray.o = h.pos + ray.d * 0.0001f; ray.dist = rd;
-                                }
-                                if (!done) { depth--; if (depth == 0) { L = mk(0, 0, 0); done = true; } }
-                            }
-                        }
-                    }
-                }
-                if (done) {
-                    for (int kk = nlev - 1; kk >= 0; kk--) {
-                        const float4 a = lv.at(kk, 0);
-                        if (__float_as_int(a.w) == 0) {
-                            const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
-                            L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
-                        } else {
-                            L = mk(0, 0, 0) + L;
-                        }
-                    }
-                    pb.rad[pid] = make_float4(L.x, L.y, L.z, 0.0f);
-                    alive = false;
-                } else {
-                    need_trace = true;
-                }
-            }
-            unsigned long long m = __ballot(need_trace);
-            if (m == 0ull) break;
-            while (m != 0ull) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                Ray ur;
-                ur.o = mk(readlane_f(ray.o.x, l), readlane_f(ray.o.y, l), readlane_f(ray.o.z, l));
-                ur.d = mk(readlane_f(ray.d.x, l), readlane_f(ray.d.y, l), readlane_f(ray.d.z, l));
-                ur.dist = readlane_f(ray.dist, l);
-                int hs, slot; f3 pos; float seg;
-                hs = -1; slot = -1; pos = mk(0, 0, 0); seg = ur.dist;
-                wave_find_intersection<STATS, STAGE, true>(sc, 0, n_shapes, prune, staged, lds, ur, hs, slot, pos, seg, ct);
-                if (lane == l) {
-                    r0 = make_float4(pos.x, pos.y, pos.z, seg);
-                    r1 = make_float4(__int_as_float(hs), __int_as_float(slot), 0.0f, 0.0f);
-                    have_hit = true;
-                }
             }
         }
     }

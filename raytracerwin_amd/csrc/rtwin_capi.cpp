@@ -90,15 +90,6 @@ struct rtw_context {
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     int batch_pos = 0;                  // rtw_render_passes: 0 = a pass on its own, 1 = first of a run, 2 = inside a run, 3 = last of a run
     bool aux_unjoined = false;          // a sky kernel of the current run is not joined yet
-    int batch_passes = 1;               // 0: every pass forks and joins the second stream by itself (for comparison)
-    int auto_fused = 1;                 // pipeline 3: below ~10 k queued paths per pass use the one-kernel-for-all-bounces variant (see render_common)
-    bool auto_fused_on = false;
-    int finish_in_trace = 0;            // pipeline 3: 1 = the last trace round folds its paths' levels itself when no material emits (measured slower: the fold
-                                        // is one lane's dependent loads per ray in a wave-per-ray loop; a shade launch does it a path per lane)
-    int resolve_inline = 1;             // pipeline 3, one sample per pixel: a path's last shading step resolves its pixel (0: the resolve kernel does)
-    int lead_split = 1;                 // pipeline 3: leading analytic shapes are tested by the shading lanes (0: by the trace waves, for comparison)
-    int direct_slots = 1;               // pipeline 3: the primary kernel shades the camera rays' hits itself (no shade(0) launch, no queue)
-    int sky_split = 1;                  // 0 = one primary kernel for every tile
     float* d_unit = nullptr;
     float* d_gamma = nullptr;
     float* d_lut = nullptr;
@@ -107,9 +98,7 @@ struct rtw_context {
     void* d_workspace = nullptr;        // per-launch queues / level store of the bounce recursion (grown on demand)
     size_t workspace_bytes = 0;
     int pipeline = 4;                   // 4 = pass-batched: screen bins + a ray per lane, K passes per set of launches (default), 3 = screen bins + a wave per secondary ray, one pass
-                                        // per set of launches, 2 = a launch per bounce, 1 = primary / path / resolve, 0 = one kernel
-    int packets = 1;                    // pipeline 1: camera rays traced as 64-ray packets inside the primary kernel
-    int path_lanes = 16;                // pipeline 1: lanes per ray in the path kernel (16, 4 or 1)
+                                        // per set of launches (the one-pass reference), 0 = one kernel, one thread per pixel (reference-order counters)
     uint32_t* h_counters = nullptr;     // pinned: queue / pending lengths copied back after each pass
     hipEvent_t counters_event = nullptr;// recorded after that copy; the value is only read once the event has completed
     bool counters_pending = false;
@@ -118,34 +107,10 @@ struct rtw_context {
     int known_paths = -1;               // queue length of the latest pass whose copy has completed
     int known_rounds[32];               // wavefront: trace-list lengths of that pass
     int cu_count = 256;
-    int wave_stage = 0;                 // pipeline 3: LDS staging of shape 0 in the trace kernels: 0 = none (measured fastest: more waves in flight
-                                        // beat LDS residency), 1..3 = levels / leaves / triangles, -1 = as much as fits
-    int wave_blocks_mul = 8;
-    int trace_block = 128;              // measured: 128 / 64-thread blocks a little faster than 256 (fewer waves coupled to one block)
     const void* clean_ws = nullptr;     // workspace and counters offset whose counters the last pass left zeroed (bins + wave pipeline)
     size_t clean_off = 0;
-    // a whole pass captured as a launch graph and replayed with the pass index on the device (rtw_render_passes)
-    struct PassGraph {
-        bool valid = false;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        const void* scene = nullptr; const void* fb = nullptr;
-        int task_rows = 0, rank = 0, world = 0, max_bounce = 0, preview = 0, sub_samples = 0;
-        uint32_t seed = 0;
-        int next_pass = -1;
-    } pass_graph;
-    int32_t* d_pass = nullptr;          // the replayed graph's pass index
-    int32_t* h_pass = nullptr;          // pinned staging word for d_pass
     int hint_period = 16;               // the queue lengths are read back every hint_period-th pass (a 256-byte copy costs the stream ~10 us; the lengths drift slowly)
     int hint_tick = 0;
-    int use_graph = 0;                  // rtw_render_passes: 1 = replay a captured pass as a launch graph (measured: no faster, the passes are GPU-bound,
-                                        // and a captured pass cannot use the second stream), 0 = launch every pass kernel by kernel
-    int debug_primary = 0;              // timing experiments only (wrong images): 1 no gamma, 2 no accumulator traffic, 4 no bins loop
-    int primary_blocks_per_cu = 64;     // pipeline 3: persistent primary kernel, blocks of 256 threads per CU
-    int wave_tail = 0;                  // pipeline 3: 1 = after the first trace round one kernel finishes the frame (measured slower: register-bound)
-    int wave_fused = 0;                 // pipeline 3: 1 = one kernel carries the paths to their end, 0 = a launch per bounce
-    int wave_paths = 0;                 // pipeline 3: paths per wave of the path kernel (0 = chosen from the queue length)
-    int path_variant = 2;               // measured fastest on MI355X (16-wide nodes through L2, 3 waves/SIMD); see DESIGN.md
     int kernel_timing = 0;              // 1: record events around the three kernels of each pass
     hipEvent_t timing_events[4] = { nullptr, nullptr, nullptr, nullptr };
     // pass-batched pipeline (pipeline 4): its own workspace (the list counters sit at its start and are left zeroed by every group)
@@ -176,11 +141,8 @@ struct rtw_context {
     int visit_budget = 384;             // one-mesh scenes: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
     int group_paths = 16 << 20;         // passes are grouped until a launch holds about this many paths ...
     int group_max = 256;                // ... and at most this many passes (a power of two)
-    int wide_below = 0;                 // trace rounds with at least wave_below and fewer than this many rays run sixteen lanes per ray on the 16-wide tree (0: never)
     int wave_below = 80000;             // a trace round with fewer rays (x 5 for trees of more than 4096 nodes) runs a wave per ray (measured with groups as two halves: C2 -3 % against 160 000; big trees keep 400 000)
     int device_build = 1;               // rtw_scene_commit builds the tree (KdNode::Build's decisions) and the layouts derived from it on the device (0: on the host)
-    int trace_persist = 1;              // one-mesh scenes: persistent trace waves that refill their lanes
-    int trace_stage = 1;                // the ray-per-lane trace kernel stages the first mesh's upper tree levels in LDS (1024-thread blocks)
     int last_pipeline = -1;             // the pipeline the latest render call actually ran (rtw_last_pass_pipeline)
     size_t workspace_limit = (size_t)24 << 30;  // a group's workspace may not exceed this (option "workspace_limit_mb"); hipMalloc failing counts as exceeding it
     bool ws_refused = false;            // the latest ensure_group_workspace was refused (limit or out of memory): the caller retries with a smaller group
@@ -291,8 +253,6 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&c->h_pass, 64, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&c->d_pass, 64));
     HIP_TRY(hipEventCreateWithFlags(&c->counters_event, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&c->h_gcounters, 256, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&c->gcounters_event, hipEventDisableTiming));
@@ -316,10 +276,6 @@ int rtw_context_destroy(rtw_context* ctx)
     if (ctx->d_unit) release_device_table(ctx->device);
     (void)hipFree(ctx->d_workspace); (void)hipFree(ctx->d_gamma); (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_stats);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->pass_graph.exec) (void)hipGraphExecDestroy(ctx->pass_graph.exec);
-    if (ctx->pass_graph.graph) (void)hipGraphDestroy(ctx->pass_graph.graph);
-    if (ctx->h_pass) (void)hipHostFree(ctx->h_pass);
-    if (ctx->d_pass) (void)hipFree(ctx->d_pass);
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
@@ -351,7 +307,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
 {
     if (!ctx || !name) return fail(RTW_ERR_INVALID, "null argument");
     if (std::strcmp(name, "pipeline") == 0) {
-        if (value < 0 || value > 4) return fail(RTW_ERR_INVALID, "pipeline must be 0 .. 4");
+        if (value != 0 && value != 3 && value != 4) return fail(RTW_ERR_INVALID, "pipeline must be 4 (pass-batched, default), 3 (one pass per set of launches) or 0 (one kernel)");
         ctx->pipeline = value;
         return RTW_OK;
     }
@@ -361,62 +317,18 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "split_paths") == 0) { ctx->split_paths = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "split_min") == 0) { ctx->split_min = value < 2 ? 2 : value; return RTW_OK; }
     if (std::strcmp(name, "budget_nodes") == 0) { ctx->budget_nodes = value < 0 ? 0 : value; return RTW_OK; }
-    if (std::strcmp(name, "wide_below") == 0) { ctx->wide_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "device_build") == 0) { ctx->device_build = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "trace_persist") == 0) { ctx->trace_persist = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "trace_stage") == 0) { ctx->trace_stage = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "group_max") == 0) {
         if (value < 1 || value > 256 || (value & (value - 1)) != 0) return fail(RTW_ERR_INVALID, "group_max must be a power of two in 1..256");
         ctx->group_max = value;
         return RTW_OK;
     }
-    if (std::strcmp(name, "trace_block") == 0) { ctx->trace_block = (value == 64 || value == 128) ? value : 256; return RTW_OK; }
-    if (std::strcmp(name, "wave_blocks_mul") == 0) { ctx->wave_blocks_mul = value < 1 ? 1 : value; return RTW_OK; }
-    if (std::strcmp(name, "wave_stage") == 0) {
-        if (value < -1 || value > 3) return fail(RTW_ERR_INVALID, "wave_stage must be -1 (automatic) or 0..3");
-        ctx->wave_stage = value;
-        return RTW_OK;
-    }
-#ifdef RTW_DEBUG_OPTIONS        // timing experiments that skip work (wrong images): not in the release library
-    if (std::strcmp(name, "debug_primary") == 0) { ctx->debug_primary = value; return RTW_OK; }
-#endif
     if (std::strcmp(name, "hint_period") == 0) { ctx->hint_period = value < 1 ? 1 : value; return RTW_OK; }
-    if (std::strcmp(name, "direct_slots") == 0) { ctx->direct_slots = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "auto_fused") == 0) { ctx->auto_fused = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "finish_in_trace") == 0) { ctx->finish_in_trace = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "batch_passes") == 0) { ctx->batch_passes = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "resolve_inline") == 0) { ctx->resolve_inline = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "lead_split") == 0) { ctx->lead_split = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "sky_split") == 0) { ctx->sky_split = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "use_graph") == 0) { ctx->use_graph = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "primary_blocks_per_cu") == 0) {
-        if (value < 1 || value > 64) return fail(RTW_ERR_INVALID, "primary_blocks_per_cu must be 1..64");
-        ctx->primary_blocks_per_cu = value;
-        return RTW_OK;
-    }
-    if (std::strcmp(name, "wave_tail") == 0) { ctx->wave_tail = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "wave_fused") == 0) {
-        if (value != 0 && value != 1) return fail(RTW_ERR_INVALID, "wave_fused must be 0 or 1");
-        ctx->wave_fused = value;
-        return RTW_OK;
-    }
-    if (std::strcmp(name, "wave_paths") == 0) {
-        if (value < 0 || value > 64) return fail(RTW_ERR_INVALID, "wave_paths must be 0 (automatic) or 1..64");
-        ctx->wave_paths = value;
-        return RTW_OK;
-    }
-    if (std::strcmp(name, "packets") == 0) { ctx->packets = value ? 1 : 0; return RTW_OK; }
-    if (std::strcmp(name, "path_variant") == 0) { ctx->path_variant = value; return RTW_OK; }
     if (std::strcmp(name, "kernel_timing") == 0) {
         if (value && !ctx->timing_events[0]) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ctx->timing_events[i]));
         ctx->kernel_timing = value ? 1 : 0;
-        return RTW_OK;
-    }
-    if (std::strcmp(name, "path_lanes") == 0) {
-        if (value != 1 && value != 4 && value != 16) return fail(RTW_ERR_INVALID, "path_lanes must be 1, 4 or 16");
-        ctx->path_lanes = value;
         return RTW_OK;
     }
     return fail(RTW_ERR_INVALID, std::string("unknown option ") + name);
@@ -466,7 +378,6 @@ int rtw_scene_destroy(rtw_scene* scene)
     if (scene->ctx) {
         (void)hipSetDevice(scene->ctx->device);
         (void)hipStreamSynchronize(scene->ctx->stream);
-        if (scene->ctx->pass_graph.scene == scene) scene->ctx->pass_graph.valid = false;      // a captured pass holds this scene's device pointers
     }
     for (void* p : scene->allocs) (void)hipFree(p);
     delete scene;
@@ -633,7 +544,7 @@ int rtw_scene_set_material(rtw_scene* scene, int shape, const rtw_material_node*
 int rtw_scene_set_traversal(rtw_scene* scene, int mode)
 {
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
-    if (mode != 0 && mode != 1) return fail(RTW_ERR_INVALID, "traversal must be 0 (binary preorder walk) or 1 (4-wide walk)");
+    if (mode != 0 && mode != 1) return fail(RTW_ERR_INVALID, "traversal must be 0 (binary preorder walk only) or 1 (accelerated walks allowed)");
     scene->traversal = mode;
     if (scene->committed && scene->ctx) {
         HIP_TRY(hipSetDevice(scene->ctx->device));
@@ -664,7 +575,7 @@ int rtw_scene_commit(rtw_scene* scene)
     if (!scene) return fail(RTW_ERR_INVALID, "scene is null");
     if (scene->committed) return fail(RTW_ERR_STATE, "scene already committed");
     if (!scene->ctx) {      // host-only scene: build the flattened trees for inspection, nothing to upload
-        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_quads(*m); rtw::build_tnodes(*m, RTW_TNODES_TOP_BUDGET); rtw::build_flat(*m); }
+        for (auto& m : scene->meshes) { rtw::build_tree(*m); rtw::build_tnodes(*m, RTW_TNODES_TOP_BUDGET); rtw::build_flat(*m); }
         scene->committed = true;
         return RTW_OK;
     }
@@ -720,17 +631,7 @@ int rtw_scene_commit(rtw_scene* scene)
             rtw::build_tree(m);
             COMMIT_MARK("host build_tree");
         }
-        rtw::build_quads(m);
-        COMMIT_MARK("host build_quads");
         if (!on_device && (rc = upload(scene, m.nodes, &d.nodes)) != RTW_OK) return rc;
-        if (m.quad_depth <= RTW_QUAD_STACK) {
-            if ((rc = upload(scene, m.quads, &d.quads)) != RTW_OK) return rc;
-            d.n_quads = (int)m.quads.size(); d.quad_depth = m.quad_depth;
-        }
-        if (m.wide_depth <= RTW_WIDE_STACK && m.wides.size() < 65536) {
-            if ((rc = upload(scene, m.wides, &d.wides)) != RTW_OK) return rc;
-            d.n_wides = (int)m.wides.size(); d.wide_depth = m.wide_depth;
-        }
         if (!on_device) {
             rtw::build_tnodes(m, RTW_TNODES_TOP_BUDGET);
             if ((rc = upload(scene, m.tnodes, &d.tnodes)) != RTW_OK) return rc;
@@ -810,23 +711,6 @@ int rtw_scene_mesh_nodes(const rtw_scene* scene, int shape, float* bounds6, int3
         if (tri) tri[i] = nd.tri >= 0 ? m.tris[(size_t)nd.tri].orig : -1;
     }
     return (int)m.nodes.size();
-}
-
-int rtw_scene_mesh_quads(const rtw_scene* scene, int shape, float* bounds24, int32_t* child4, int max_quads)
-{
-    if (!scene || shape < 0 || shape >= (int)scene->meshes.size()) return fail(RTW_ERR_INVALID, "bad shape index");
-    if (!scene->committed) return fail(RTW_ERR_STATE, "scene not committed");
-    const rtw::HostMesh& m = *scene->meshes[(size_t)shape];
-    const int n = (int)m.quads.size() < max_quads ? (int)m.quads.size() : max_quads;
-    for (int i = 0; i < n; i++) {
-        const RtwQuad& q = m.quads[(size_t)i];
-        if (bounds24) std::memcpy(bounds24 + (size_t)i * 24, q.min_x, 96);
-        if (child4) for (int k = 0; k < 4; k++) {
-            const int32_t c = q.child[k];
-            child4[(size_t)i * 4 + k] = (c < 0 && c != RTW_QUAD_EMPTY) ? -1 - m.tris[(size_t)(-1 - c)].orig : c;
-        }
-    }
-    return (int)m.quads.size();
 }
 
 int rtw_scene_mesh_flat(const rtw_scene* scene, int shape, int level, float* boxes6, int max_entries)
@@ -985,7 +869,6 @@ int rtw_framebuffer_wrap(rtw_context* ctx, int width, int height, void* accum_de
 int rtw_framebuffer_destroy(rtw_framebuffer* fb)
 {
     if (!fb) return RTW_OK;
-    if (fb->ctx && fb->ctx->pass_graph.fb == fb) fb->ctx->pass_graph.valid = false;
     if (fb->owned) {
         (void)hipSetDevice(fb->ctx->device);
         (void)hipStreamSynchronize(fb->ctx->stream);
@@ -1259,11 +1142,10 @@ static int check_render_args(const rtw_scene* scene, const rtw_framebuffer* fb, 
     return RTW_OK;
 }
 
-// Can this scene / context go through the pass-batched pipeline?  (The reference-order walk used for work counters, traversal 0,
-// and the "packets 0" comparison mode stay with the older kernels.)
+// Can this scene / context go through the pass-batched pipeline?  (The reference-order walk used for work counters, traversal 0, stays with the single kernel.)
 static bool group_pipeline_ok(const rtw_scene* scene)
 {
-    return scene->ctx->pipeline == 4 && scene->traversal != 0 && scene->ctx->packets != 0;
+    return scene->ctx->pipeline == 4 && scene->traversal != 0;
 }
 
 // how many of the `remaining` passes the next group takes: enough for about group_paths paths per launch, a power of two of slots
@@ -1351,7 +1233,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     {   // the scene's leading spheres / planes / capsules / triangles are tested by the lane that sets a segment up (group_lead_query)
         int lead = 0;
         while (lead < (int)scene->meshes.size() && scene->meshes[(size_t)lead]->kind != RTW_SHAPE_MESH) lead++;
-        p.lead_shapes = cx->lead_split ? lead : 0;
+        p.lead_shapes = lead;
     }
     g.rp = p;
     const bool carry = scene->texture_carry;
@@ -1361,7 +1243,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
     rtw::GroupTuning tune;
     tune.capacity = capacity;
-    tune.aux_stream = cx->sky_split ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
+    tune.aux_stream = cx->aux_stream; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
     tune.do_fork = cx->batch_pos == 0 || cx->batch_pos == 1 || !cx->aux_unjoined;
     tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
     tune.gamma_thr = cx->d_gamma;
@@ -1370,17 +1252,13 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     if (cx->lane == 0) tune.sky_passes = cx->lane_sky_passes;
     else { tune.no_sky = true; tune.resolve_after = cx->split_mid; tune.aux_stream = nullptr; }
     tune.cu_count = cx->cu_count;
-    if (cx->trace_stage) {      // the first mesh's upper tree levels live in the trace blocks' LDS
+    {      // the first mesh's upper tree levels live in the trace blocks' LDS
         for (size_t k = 0; k < scene->meshes.size(); k++)
             if (scene->meshes[k]->kind == RTW_SHAPE_MESH && scene->meshes[k]->tnodes_top > 0) { tune.staged_shape = (int)k; tune.staged_top = scene->meshes[k]->tnodes_top; tune.staged_all = tune.staged_top == (int)scene->meshes[k]->tnodes.size(); break; }
     }
     tune.single_mesh = scene->meshes.size() == 1 && scene->meshes[0]->kind == RTW_SHAPE_MESH && !scene->meshes[0]->nodes.empty();
-    tune.persist = cx->trace_persist != 0;
     // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
     tune.visit_budget = (cx->visit_budget > 0 && tune.single_mesh && scene->meshes[0]->nodes.size() > (size_t)cx->budget_nodes) ? cx->visit_budget : INT32_MAX;
-    tune.wide_below = cx->wide_below;
-    tune.wide_ok = true;
-    for (const auto& m : scene->meshes) if (m->kind == RTW_SHAPE_MESH && (m->wides.empty() || m->wide_depth > RTW_WIDE_STACK || m->wides.size() >= 65536)) tune.wide_ok = false;
     tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 5 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
     tune.timing = (cx->kernel_timing && cx->lane == 0) ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
@@ -1418,141 +1296,78 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
 }
 
 // ---- the hot path -------------------------------------------------------------------------------------------
+// One pass through pipeline 3 (bins + a wave per secondary ray; the one-pass reference of the pass-batched pipeline) or pipeline 0 (one kernel, one
+// thread per pixel: every frame shape and range, the reference-order walk for the work counters).
 static int render_common(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams& p, int max_bounce, int use_base_color,
-                         int pass_index, int sub_samples, uint32_t seed, bool capturing = false, bool* used_bins_pipeline = nullptr)
+                         int pass_index, int sub_samples, uint32_t seed)
 {
-    if (fb->ctx != scene->ctx) return fail(RTW_ERR_INVALID, "scene and framebuffer belong to different contexts");
-    if (max_bounce < 0 || max_bounce > RTW_MAX_BOUNCE) return fail(RTW_ERR_LIMIT, "max_bounce out of range");
-    if (sub_samples < 1 || sub_samples > 4) return fail(RTW_ERR_INVALID, "sub_samples must be 1..4");
-    if (pass_index < 0) return fail(RTW_ERR_INVALID, "pass_index must be >= 0");
+    int rc = check_render_args(scene, fb, max_bounce, pass_index, sub_samples); if (rc != RTW_OK) return rc;
     p.width = fb->width; p.height = fb->height;
     p.max_bounce = max_bounce; p.preview = use_base_color ? 1 : 0; p.pass_index = pass_index; p.sub_samples = sub_samples; p.seed = seed;
+    rtw_context* cx = scene->ctx;
     hipError_t e;
-    // the bins + wave pipeline needs whole rows, the flat hierarchy (traversal != 0) and a frame that tiles; else pipeline 2
-    int pipeline = scene->ctx->pipeline > 3 ? 3 : scene->ctx->pipeline;
-    // spheres / planes / capsules are built into the bins + wave pipeline and the single kernel; the two older pipelines
-    // (options 1 and 2) then run as the single kernel, and so does a scene whose analytic hits can inherit a texel
-    const int fallback = scene->has_analytic ? 0 : 2;
-    if (scene->has_analytic && (pipeline == 1 || pipeline == 2)) pipeline = 0;
+    // the bins + wave pipeline needs whole rows, the flat hierarchy (traversal != 0) and a frame that tiles; a scene whose analytic hits can inherit a texel
+    // (one RayHitResult serves all shapes) goes through the single kernel; so does everything else that does not fit
+    int pipeline = cx->pipeline >= 3 ? 3 : 0;
     if (scene->texture_carry) pipeline = 0;
     int sky_job0 = 0;
     if (pipeline == 3) {
         RtwRenderParams tiled = p;
         rtw_scene::BinSet* bs = nullptr;
-        if (scene->traversal != 0 && scene->ctx->packets != 0 && choose_tiles(tiled) &&
-            scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &bs) == RTW_OK) {
+        if (scene->traversal != 0 && choose_tiles(tiled) && scene_bins(scene, p.width, p.height, tiled.tile_w, tiled.tile_h, &bs) == RTW_OK) {
             p = tiled; p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
             const rtw_scene::JobTable* jt = nullptr;
             if (scene_job_table(scene, *bs, p, sub_samples, &jt) != RTW_OK) jt = nullptr;
             p.tile_order = jt ? jt->d_order : nullptr;
             p.n_jobs = jt ? jt->n_jobs : 0;
             sky_job0 = jt ? jt->n_busy : 0;
-            if (used_bins_pipeline) *used_bins_pipeline = true;
         } else {
-            pipeline = fallback;
+            pipeline = 0;
         }
     }
-    if (pipeline >= 1) {
+    if (pipeline == 3) {
         rtw::PipelineLayout layout;
-        rtw::pipeline_workspace_bytes(p.count, max_bounce, &layout);
-        int rc = ensure_workspace(scene->ctx, pipeline >= 2 ? layout.wf_total : layout.total); if (rc != RTW_OK) return rc;
-        int lds_quads = 0;
-        if (scene->ctx->path_lanes == 4 && scene->traversal != 0 && !scene->meshes.empty() && scene->meshes[0]->quad_depth <= RTW_QUAD_STACK) {
-            lds_quads = (int)scene->meshes[0]->quads.size();
-            if (lds_quads > RTW_LDS_QUAD_BUDGET) lds_quads = 0;        // all or nothing: a larger tree is read through L2
-        }
+        rc = ensure_workspace(cx, rtw::pipeline_workspace_bytes(p.count, max_bounce, &layout)); if (rc != RTW_OK) return rc;
         rtw::PipelineTuning tune;
-        tune.path_lanes = scene->ctx->path_lanes;
-        tune.lds_wide_count = 0;
-        if (tune.path_lanes == 16) {
-            const rtw::HostMesh* m0 = scene->meshes.empty() ? nullptr : scene->meshes[0].get();
-            if (!m0 || m0->wides.empty() || m0->wide_depth > RTW_WIDE_STACK || m0->wides.size() >= 65536 || scene->traversal == 0) tune.path_lanes = 4;
-            else if ((int)m0->wides.size() <= RTW_LDS_WIDE_BUDGET) tune.lds_wide_count = (int)m0->wides.size();
-        }
-        if (tune.path_lanes != 4) lds_quads = 0;
         // queue length of the previous pass with the same launch shape (a stale or missing value only costs speed)
-        rtw_context* cx = scene->ctx;
         const long long shape = (long long)p.count * 64 + sub_samples;
-        if (capturing) p.pass_ptr = cx->d_pass;              // the graph's kernels read the pass index from the device
-        if (!capturing && cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
+        if (cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
             cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
             for (int r = 0; r < 32; r++) cx->known_rounds[r] = (int)cx->h_counters[4 + r];
         }
         tune.expected_paths = (cx->known_shape == shape) ? cx->known_paths : -1;
         for (int r = 0; r < 32; r++) tune.round_hint[r] = (cx->known_shape == shape) ? cx->known_rounds[r] : -1;
-        p.packets = (cx->packets != 0 && scene->traversal != 0) ? 1 : 0;
-        p.wavefront = (pipeline >= 2 && p.packets) ? (pipeline == 3 ? 2 : 1) : 0;
-        tune.aux_stream = (cx->sky_split && !capturing) ? cx->aux_stream : nullptr; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
+        tune.aux_stream = cx->aux_stream; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
         tune.sky_job0 = sky_job0; tune.gamma_thr = cx->d_gamma;
         tune.do_fork = cx->batch_pos == 0 || cx->batch_pos == 1 || !cx->aux_unjoined;      // (a run whose earlier passes launched no sky kernel has not forked yet)
         tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
-        // Few paths (a rank's share of a small frame at 8 or more ranks): every launch of the per-bounce pipeline sits on its ~9 us floor, and the
-        // one-kernel-for-all-bounces variant, slower at full size, wins (C2 at 8 ranks: 0.074 vs 0.080 ms per pass).  Chosen from the previous pass's
-        // queue length, with some hysteresis (the two variants count the queue a little differently).
-        int fused = cx->wave_fused;
-        if (!fused && !cx->wave_tail && cx->auto_fused && pipeline == 3 && !scene->has_analytic && !capturing && !cx->stats_enabled && !cx->kernel_timing &&
-            tune.expected_paths >= 0 && tune.expected_paths < (cx->auto_fused_on ? 13000 : 10000)) fused = 1;
-        cx->auto_fused_on = fused && !cx->wave_fused;
-        tune.wave_stage = 0; tune.wave_stage_bytes = 0; tune.wave_blocks = cx->cu_count; tune.wave_fused = fused; tune.wave_tail = cx->wave_tail; tune.wave_blocks_mul = cx->wave_blocks_mul; tune.trace_block = cx->trace_block; tune.primary_blocks_per_cu = cx->primary_blocks_per_cu;
-        if (p.wavefront == 2 && !scene->meshes.empty()) {
-            // what of shape 0 fits in a CU's LDS beside the waves' lists (16 KiB): the upper levels, the leaves' boxes, the triangles
-            const rtw::HostMesh& m0 = *scene->meshes[0];
-            const size_t budget = 160 * 1024 - 16 * 1024 - 2048;
-            const size_t b1 = (size_t)6 * 4 * ((size_t)m0.flat_pad[2] + (size_t)m0.flat_pad[1]);
-            const size_t b2 = b1 + (size_t)6 * 4 * (size_t)m0.flat_pad[0];
-            const size_t b3 = b2 + m0.tris.size() * sizeof(RtwTri);
-            int stage = m0.flat_n[0] <= 0 ? 0 : (b3 <= budget ? 3 : (b2 <= budget ? 2 : (b1 <= budget ? 1 : 0)));
-            if (cx->wave_stage >= 0 && cx->wave_stage < stage) stage = cx->wave_stage;
-            tune.wave_stage = stage;
-            tune.wave_stage_bytes = stage == 3 ? b3 : (stage == 2 ? b2 : (stage == 1 ? b1 : 0));
-        }
-        if (p.wavefront == 2) {
-            int B = cx->wave_paths;
-            if (B == 0) {       // enough waves to fill the chip (1024 SIMDs, several waves each), at most 16 paths per wave
-                const int expect = tune.expected_paths >= 0 ? tune.expected_paths : 1 << 20;
-                const int resident = tune.wave_stage > 0 ? cx->cu_count * 16 : 8192;
-                B = (expect + resident - 1) / resident;
-                if (B < 2) B = 2;
-                if (B > 32) B = 32;
-            }
-            p.wave_paths = B;
-            p.pad_params = cx->debug_primary;
-        }
+        tune.cu_count = cx->cu_count;
         tune.timing = cx->kernel_timing ? cx->timing_events : nullptr;
-        tune.path_variant = cx->path_variant;
-        const size_t coff = rtw::pipeline_counters_offset(p.count, max_bounce);
-        p.self_clean = p.wavefront == 2 ? 1 : 0;
-        p.direct_slots = (p.wavefront == 2 && cx->direct_slots && !fused && !cx->wave_tail) ? 1 : 0;
-        // one sample per pixel: the lane that ends a path resolves its pixel (no pending list, no resolve launch)
-        p.resolve_inline = (p.direct_slots && cx->resolve_inline && sub_samples == 1 && max_bounce >= 2) ? 1 : 0;
         {   // leading spheres / planes / capsules are tested by the lane that sets a segment up (see RtwRenderParams::lead_shapes)
             int lead = 0;
             while (lead < (int)scene->meshes.size() && scene->meshes[(size_t)lead]->kind != RTW_SHAPE_MESH) lead++;
-            p.lead_shapes = (p.direct_slots && cx->lead_split) ? lead : 0;
+            p.lead_shapes = lead;
             tune.has_analytic = scene->has_analytic;
-            tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();       // nothing is left for the trace kernels
+            tune.skip_trace = lead > 0 && lead == (int)scene->meshes.size();       // nothing is left for the trace kernels
         }
-        // no Emissive material anywhere, finite material colours, no preview, no counters: the last trace round can finish its paths
-        tune.finish_in_trace = cx->finish_in_trace && p.direct_slots && !scene->has_analytic && !scene->has_emissive && scene->materials_finite &&
-                               !p.preview && !cx->stats_enabled && max_bounce >= 2;
-        tune.counters_clean = p.self_clean && cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
+        const size_t coff = layout.counters_off;
+        tune.counters_clean = cx->clean_ws == cx->d_workspace && cx->clean_off == coff && cx->d_workspace != nullptr;
         cx->clean_ws = nullptr;
-        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, lds_quads, tune, scene->ctx->stats_enabled, scene->ctx->stream);
-        if (e == hipSuccess && p.self_clean) { cx->clean_ws = cx->d_workspace; cx->clean_off = coff; }
-        if (e == hipSuccess && !cx->counters_pending && !capturing && (cx->known_shape != shape || (cx->hint_tick++ % cx->hint_period) == 0)) {     // one copy in flight at a time; its value is used once it has landed
-            const size_t off = coff + (p.self_clean ? 256 : 0);       // a self-cleaning pass files its counters 64 words further
-            if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + off, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
+        e = (hipError_t)rtw::launch_render_pipeline(scene->d_scene, fb->accum, fb->argb, cx->d_workspace, p, tune, cx->stats_enabled, cx->stream);
+        if (e == hipSuccess) { cx->clean_ws = cx->d_workspace; cx->clean_off = coff; }
+        if (e == hipSuccess && !cx->counters_pending && (cx->known_shape != shape || (cx->hint_tick++ % cx->hint_period) == 0)) {     // one copy in flight at a time; its value is used once it has landed
+            if (hipMemcpyAsync(cx->h_counters, (char*)cx->d_workspace + coff + 256, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&       // (the pass files its counters 64 words further)
                 hipEventRecord(cx->counters_event, cx->stream) == hipSuccess) {
                 cx->counters_pending = true; cx->counters_shape = shape;
             }
         }
     } else {
-        int rc = ensure_workspace(scene->ctx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
-        scene->ctx->clean_ws = nullptr;
-        e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, scene->ctx->d_workspace, p, scene->ctx->stats_enabled, scene->ctx->stream);
+        rc = ensure_workspace(cx, rtw::level_workspace_bytes(p.count, max_bounce)); if (rc != RTW_OK) return rc;
+        cx->clean_ws = nullptr;
+        e = (hipError_t)rtw::launch_render(scene->d_scene, fb->accum, fb->argb, cx->d_workspace, p, cx->stats_enabled, cx->stream);
     }
     if (e != hipSuccess) return hip_fail(e, "render_kernel launch");
-    scene->ctx->last_pipeline = pipeline;
+    cx->last_pipeline = pipeline;
     return RTW_OK;
 }
 
@@ -1600,9 +1415,6 @@ int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int r
 }
 
 // n_passes accumulated passes (UpdateBitmapPixels' sample loop, Src/RayTracerProgram.cpp:317-361) over this rank's tasks.
-// The first passes are launched kernel by kernel (they also tell the queue lengths the launches are sized from); once
-// those are known, ONE pass is captured as a launch graph whose kernels take the pass index from a device word that the
-// pass's last kernel advances, and every further pass is a single graph launch.
 int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world, int max_bounce, int use_base_color,
                       int first_pass, int n_passes, int sub_samples, uint32_t seed)
 {
@@ -1678,25 +1490,10 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
         cx->group_cap = 0;
         return RTW_OK;
     }
-    rtw_context::PassGraph& g = cx->pass_graph;
+    // pipelines 3 / 0: a pass per set of launches; the passes of this call form a run (the second stream is forked before the first and joined after the last)
     for (int i = 0; i < n_passes; i++) {
-        const int pass = first_pass + i;
-        const bool same = g.valid && g.scene == scene && g.fb == fb && g.task_rows == task_rows && g.rank == rank && g.world == world &&
-                          g.max_bounce == max_bounce && g.preview == (use_base_color ? 1 : 0) && g.sub_samples == sub_samples && g.seed == seed;
-        if (same && cx->use_graph && !cx->stats_enabled && !cx->kernel_timing && cx->clean_ws != nullptr && cx->clean_ws == cx->d_workspace) {
-            if (g.next_pass != pass) {           // a new sequence: set the device's pass index
-                *cx->h_pass = pass;
-                HIP_TRY(hipMemcpyAsync(cx->d_pass, cx->h_pass, sizeof(int32_t), hipMemcpyHostToDevice, cx->stream));
-                HIP_TRY(hipStreamSynchronize(cx->stream));      // h_pass may be rewritten by the next call
-            }
-            HIP_TRY(hipGraphLaunch(g.exec, cx->stream));
-            g.next_pass = pass + 1;
-            continue;
-        }
-        // passes launched kernel by kernel inside this call form a run: the second stream is forked before the first and joined after the last
-        const bool run = cx->batch_passes && !cx->use_graph && n_passes > 1;
-        cx->batch_pos = !run ? 0 : (i + 1 == n_passes ? 3 : (i == 0 ? 1 : 2));
-        rc = rtw_render_tasks(scene, fb, task_rows, rank, world, max_bounce, use_base_color, pass, sub_samples, seed);
+        cx->batch_pos = n_passes == 1 ? 0 : (i + 1 == n_passes ? 3 : (i == 0 ? 1 : 2));
+        rc = rtw_render_tasks(scene, fb, task_rows, rank, world, max_bounce, use_base_color, first_pass + i, sub_samples, seed);
         cx->batch_pos = 0;
         if (cx->aux_unjoined && (rc != RTW_OK || i + 1 == n_passes)) {      // the run ends here (an error, or a last pass that launched no sky kernel)
             (void)hipEventRecord(cx->join_event, cx->aux_stream);
@@ -1704,37 +1501,6 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
             cx->aux_unjoined = false;
         }
         if (rc != RTW_OK) return rc;
-        if (!cx->use_graph || cx->stats_enabled || cx->kernel_timing || cx->pipeline < 3 || i + 1 >= n_passes) continue;
-        // wait for this pass's queue lengths, then capture the next pass
-        if (cx->counters_pending) { HIP_TRY(hipEventSynchronize(cx->counters_event)); }
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
-        g.valid = false;
-        // a dry run outside the capture settles everything that may allocate or synchronise (workspace, bins) and picks up the lengths
-        RtwRenderParams p; std::memset(&p, 0, sizeof p);
-        const int n_tasks = (fb->height + task_rows - 1) / task_rows;
-        const int mine = n_tasks > rank ? (n_tasks - rank + world - 1) / world : 0;
-        p.begin = 0; p.task_rows = task_rows; p.rank = rank; p.world = world;
-        p.count = world == 1 ? fb->width * fb->height : mine * task_rows * fb->width;
-        *cx->h_pass = pass + 1;
-        HIP_TRY(hipMemcpyAsync(cx->d_pass, cx->h_pass, sizeof(int32_t), hipMemcpyHostToDevice, cx->stream));
-        HIP_TRY(hipStreamSynchronize(cx->stream));
-        if (cx->counters_pending && hipEventQuery(cx->counters_event) == hipSuccess) {
-            cx->known_paths = (int)cx->h_counters[0]; cx->known_shape = cx->counters_shape; cx->counters_pending = false;
-            for (int r = 0; r < 32; r++) cx->known_rounds[r] = (int)cx->h_counters[4 + r];
-        }
-        bool bins = false;
-        HIP_TRY(hipStreamBeginCapture(cx->stream, hipStreamCaptureModeRelaxed));
-        RtwRenderParams pc = p;
-        rc = render_common(scene, fb, pc, max_bounce, use_base_color, pass + 1, sub_samples, seed, true, &bins);
-        hipGraph_t graph = nullptr;
-        const hipError_t ce = hipStreamEndCapture(cx->stream, &graph);
-        if (rc != RTW_OK || ce != hipSuccess || !graph || !bins) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); continue; }
-        hipGraphExec_t exec = nullptr;
-        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) { (void)hipGraphDestroy(graph); (void)hipGetLastError(); continue; }
-        g.graph = graph; g.exec = exec; g.valid = true;
-        g.scene = scene; g.fb = fb; g.task_rows = task_rows; g.rank = rank; g.world = world; g.max_bounce = max_bounce;
-        g.preview = use_base_color ? 1 : 0; g.sub_samples = sub_samples; g.seed = seed; g.next_pass = pass + 1;
     }
     return RTW_OK;
 }
@@ -1796,7 +1562,6 @@ int rtw_context_trim(rtw_context* ctx)
     if (ctx->d_group_ws) { (void)hipFree(ctx->d_group_ws); ctx->d_group_ws = nullptr; ctx->group_ws_bytes = 0; ctx->group_clean = false; }
     if (ctx->d_group_ws2) { (void)hipFree(ctx->d_group_ws2); ctx->d_group_ws2 = nullptr; ctx->group_ws2_bytes = 0; ctx->group_clean2 = false; }
     if (ctx->d_workspace) { (void)hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_bytes = 0; ctx->clean_ws = nullptr; }
-    ctx->pass_graph.valid = false;
     return RTW_OK;
 }
 int rtw_context_fallbacks(const rtw_context* ctx) { return ctx ? ctx->fallbacks : 0; }

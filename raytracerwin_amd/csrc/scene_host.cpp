@@ -330,95 +330,6 @@ void build_tree(HostMesh& m)
 }
 
 // ---------------------------------------------------------------------------------------
-// 4-wide collapse.  A quad node stands for one internal binary node; its slots are descendants
-// of that node in left-to-right order, obtained by repeatedly replacing the internal slot with
-// the largest box by its two children while at most 4 slots result.  Testing a slot's own box is
-// enough: a ray that hits a node's box hits every ancestor's box too (the slab test is monotone
-// in the box bounds and ancestors' bounds enclose it exactly), so skipping intermediate boxes
-// cannot admit a leaf the reference would not test.
-// ---------------------------------------------------------------------------------------
-namespace {
-// slots (binary nodes, left to right) of every wide node, breadth-first; children[q][k] = wide index or -1
-struct Collapsed { std::vector<std::vector<int>> slots, children; int depth = 0; };
-
-Collapsed collapse_tree(const HostMesh& m, size_t width)
-{
-    Collapsed out;
-    if (m.nodes.empty()) return out;
-    auto is_leaf = [&](int n) { return m.nodes[(size_t)n].tri >= 0; };
-    // weight of a slot = leaves below it (a full binary tree in preorder: subtree of n spans [n, skip))
-    auto area = [&](int n) { return (float)((m.nodes[(size_t)n].skip - n + 1) / 2); };
-    auto make_slots = [&](int n) {
-        std::vector<int> sl;
-        if (is_leaf(n)) { sl.push_back(n); return sl; }       // a one-triangle mesh: the root is a leaf
-        const int l = n + 1, r = m.nodes[(size_t)l].skip;
-        sl = { l, r };
-        // a subtree that fits one wide node is kept whole (it becomes a full node of leaves one level down)
-        // unless the node being built fits entirely; only larger subtrees are split here
-        const bool fits = area(n) <= (float)width;
-        for (;;) {
-            int best = -1; float best_area = -1.0f;
-            for (size_t k = 0; k < sl.size(); k++)
-                if (!is_leaf(sl[k]) && (fits || area(sl[k]) > (float)width) && area(sl[k]) > best_area) { best = (int)k; best_area = area(sl[k]); }
-            if (best < 0 || sl.size() + 1 > width) break;
-            const int n2 = sl[(size_t)best], l2 = n2 + 1, r2 = m.nodes[(size_t)l2].skip;
-            sl[(size_t)best] = l2;
-            sl.insert(sl.begin() + best + 1, r2);
-        }
-        return sl;
-    };
-    std::vector<int> depth_of;
-    out.slots.push_back(make_slots(0));
-    depth_of.push_back(1);
-    for (size_t qi = 0; qi < out.slots.size(); qi++) {
-        const std::vector<int> sl = out.slots[qi];
-        if (depth_of[qi] > out.depth) out.depth = depth_of[qi];
-        std::vector<int> ch(sl.size(), -1);
-        for (size_t k = 0; k < sl.size(); k++) {
-            if (is_leaf(sl[k])) continue;
-            ch[k] = (int)out.slots.size();
-            out.slots.push_back(make_slots(sl[k]));
-            depth_of.push_back(depth_of[qi] + 1);
-        }
-        out.children.push_back(ch);
-    }
-    return out;
-}
-
-template <typename Node, int W>
-void fill_wide(const HostMesh& m, const Collapsed& c, std::vector<Node>& dst)
-{
-    dst.resize(c.slots.size());
-    for (size_t qi = 0; qi < c.slots.size(); qi++) {
-        Node& q = dst[qi];
-        std::memset(&q, 0, sizeof(Node));
-        for (int k = 0; k < W; k++) {
-            q.min_x[k] = q.min_y[k] = q.min_z[k] = FLT_MAX;
-            q.max_x[k] = q.max_y[k] = q.max_z[k] = -FLT_MAX;
-            q.child[k] = RTW_QUAD_EMPTY;
-        }
-        const std::vector<int>& sl = c.slots[qi];
-        for (size_t k = 0; k < sl.size(); k++) {
-            const RtwNode& b = m.nodes[(size_t)sl[k]];
-            q.min_x[k] = b.min_x; q.min_y[k] = b.min_y; q.min_z[k] = b.min_z;
-            q.max_x[k] = b.max_x; q.max_y[k] = b.max_y; q.max_z[k] = b.max_z;
-            q.child[k] = b.tri >= 0 ? -1 - b.tri : c.children[qi][k];
-        }
-    }
-}
-}  // namespace
-
-void build_quads(HostMesh& m)
-{
-    const Collapsed c4 = collapse_tree(m, 4);
-    fill_wide<RtwQuad, 4>(m, c4, m.quads);
-    m.quad_depth = c4.depth;
-    const Collapsed c16 = collapse_tree(m, 16);
-    fill_wide<RtwWide, 16>(m, c16, m.wides);
-    m.wide_depth = c16.depth;
-}
-
-// ---------------------------------------------------------------------------------------
 // The tree with explicit links for the ray-per-lane walk.  Depth limit D = the deepest level such that the nodes of depth <= D
 // number at most top_budget; those come first (preorder), then, for every internal node of depth D in preorder, the nodes below it
 // (preorder).  A record's links name records of this array; following them visits the nodes in the order KdNode::TestRayIntersection

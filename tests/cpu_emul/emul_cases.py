@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"workspace_limit_mb": 0, "wave_below": 80000, "trace_persist": 1, "trace_stage": 1, "group_max": 256, "device_build": 1, "visit_budget": 384, "wide_below": 0, "split_min": 8, "split_paths": 400000}
+DEFAULTS = {"workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 
@@ -118,10 +118,8 @@ def case_shapes(ctx):
 def case_trace_variants(ctx):
     m = mesh("TorusKnot", SC.reflective())
     frame_case(ctx, "wave-per-ray trace kernel", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 1 << 30)])
-    frame_case(ctx, "ray-per-lane, one pass of the list", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("trace_persist", 0)])
-    frame_case(ctx, "ray-per-lane, nothing staged", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("trace_stage", 0)])
+    frame_case(ctx, "ray-per-lane, persistent waves", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0)])
     frame_case(ctx, "ray-per-lane, budget 8 + overflow", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 8)])
-    frame_case(ctx, "16 lanes per ray", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wide_below", 1 << 30)])
     frame_case(ctx, "groups of 2 passes", m, 64, 48, 1, 4, 5, options=[("device_build", 0), ("group_max", 2)])
 
 
@@ -168,15 +166,14 @@ def case_device_build(ctx):
             s = R.RayTracerScene(ctx)
             s.AddShape(R.RMeshShape.Create(asset(name + ".obj")), R.SurfaceMaterial_Diffuse())
             s.commit()
-            out[dev] = (s.mesh_nodes(), [s.mesh_flat(l) for l in range(3)], s.mesh_quads(), s.mesh_bins(64, 48, 8, 8))
+            out[dev] = (s.mesh_nodes(), [s.mesh_flat(l) for l in range(3)], s.mesh_bins(64, 48, 8, 8))
             s.close()
             print("  %-34s device_build %d  (%.1f s)" % (name, dev, time.time() - t0), flush=True)
         ctx.set_option("device_build", 1)
         same = lambda u, v: np.array_equal(np.ascontiguousarray(u).view(np.uint8), np.ascontiguousarray(v).view(np.uint8))  # noqa: E731
-        (n1, f1, q1, b1), (n0, f0, q0, b0) = out[1], out[0]
+        (n1, f1, b1), (n0, f0, b0) = out[1], out[0]
         assert all(same(x, y) for x, y in zip(n1, n0)), name
         assert all(same(x, y) for x, y in zip(f1, f0)), name
-        assert all(same(x, y) for x, y in zip(q1, q0)), name
         assert (b1 is None) == (b0 is None) and (b1 is None or all(same(x, y) for x, y in zip(b1, b0))), name
     frame_case(ctx, "frame over device-built tree + bins", mesh("TorusKnot", SC.reflective()), 64, 48, 1, 3, 2)
 

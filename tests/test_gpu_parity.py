@@ -304,51 +304,32 @@ def test_two_meshes_in_one_scene(ctx, oracle_mod):
 
 @pytest.mark.parametrize("mesh,ns,depth,preview", [("TorusKnot", 1, 4, 0), ("unitychan", 4, 4, 0), ("BlenderMonkey", 3, 0, 0),
                                                    ("TorusKnot", 4, 3, 1)])
-def test_compacted_pipeline_equals_single_kernel(ctx, mesh, ns, depth, preview):
-    """The default three-launch pipeline (primary / path queue / resolve) and the one-thread-per-pixel
-    kernel give the same bits and the same work counters; 1280x720, two accumulated passes."""
+def test_the_three_pipelines_give_the_same_bits_and_counters(ctx, mesh, ns, depth, preview):
+    """The pass-batched default (4; also with every trace round forced through the ray-per-lane kernels, and through the wave-per-ray kernel), the one-pass
+    bins + wave pipeline (3) and the one-thread-per-pixel kernel (0) give the same bits and the same per-ray work counters; 1280x720, two accumulated passes."""
     W, H = 1280, 720
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
     out = []
-    # (pipeline, packets, path_lanes, wave_fused, wave_stage): 3 = screen bins + a wave per secondary ray
-    for mode, packets, lanes, fused, stage in ((0, 0, 4, 0, -1), (1, 0, 4, 0, -1), (1, 0, 1, 0, -1), (1, 1, 4, 0, -1), (1, 1, 1, 0, -1), (1, 0, 16, 0, -1),
-                                               (1, 1, 16, 0, -1), (2, 1, 16, 0, -1), (3, 1, 16, 0, -1), (3, 1, 16, 1, -1), (3, 1, 16, 0, 0),
-                                               (3, 1, 16, 0, 1), (3, 1, 16, 1, 2), (3, 1, 16, 2, -1), (3, 1, 16, 2, 2), (4, 1, 16, 0, -1), (4, 1, 16, 0, 0)):
+    for mode, wave_below in ((0, 80000), (3, 80000), (4, 80000), (4, 0), (4, 1 << 30)):
         ctx.set_option("pipeline", mode)
-        ctx.set_option("packets", packets)
-        ctx.set_option("path_lanes", lanes)
-        ctx.set_option("wave_fused", 1 if fused == 1 else 0)         # fused: 1 = one kernel for all bounces, 2 = one kernel after the first trace round
-        ctx.set_option("wave_tail", 1 if fused == 2 else 0)
-        ctx.set_option("wave_stage", stage)
-        ctx.set_option("direct_slots", 0 if (mode == 3 and stage == 1) else 1)       # the stage-1 run also takes the queue + shade(0) route
-        ctx.set_option("sky_split", 0 if (mode in (3, 4) and stage == 0) else 1)     # the stage-0 run also keeps every tile in one primary kernel
-        ctx.set_option("trace_persist", 0 if (mode == 4 and stage == 0) else 1)      # ... and, pass-batched, walks without refilling lanes, nothing staged, no wave-per-ray rounds
-        ctx.set_option("trace_stage", 0 if (mode == 4 and stage == 0) else 1)
-        ctx.set_option("wave_below", 0 if (mode == 4 and stage == 0) else 100000)
+        ctx.set_option("wave_below", wave_below)
         ctx.stats_enable(True)
         ctx.stats_reset()
         a, b = render_frame(ctx, s, W, H, ns, depth, preview, 4321, 0, 2)
         out.append((a, b, ctx.stats()))
         ctx.stats_enable(False)
     ctx.set_option("pipeline", DEFAULT_PIPELINE)
-    ctx.set_option("packets", 1)
-    ctx.set_option("path_lanes", 16)
-    ctx.set_option("wave_fused", 0)
-    ctx.set_option("wave_tail", 0)
-    ctx.set_option("wave_stage", 0)
-    ctx.set_option("direct_slots", 1)
-    ctx.set_option("sky_split", 1)
+    ctx.set_option("wave_below", 80000)
     keys = ("rays", "shaded_hits", "tex_samples", "camera_rays")     # box / triangle test counts depend on the walk
     for o in out[1:]:
         assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
         assert [out[0][2][k] for k in keys] == [o[2][k] for k in keys]
-    assert out[0][2] == out[1][2] == out[2][2]
 
 
 @pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4), ("BlenderMonkey", 4, 6)])
-def test_quad_walk_equals_binary_walk(ctx, mesh, ns, depth):
-    """traversal=1 (4-wide, candidates gathered then triangle-tested in order) vs traversal=0 (binary preorder
-    walk in the reference's visit order), with and without pruning: same bits at 1920x1080."""
+def test_accelerated_walks_equal_the_reference_order_walk(ctx, mesh, ns, depth):
+    """traversal=1 (screen bins, link tree and flat hierarchy: candidates gathered, then triangle-tested in order) vs traversal=0 (the binary
+    preorder walk in the reference's visit order, one thread per pixel), with and without pruning: same bits at 1920x1080."""
     W, H = 1920, 1080
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse())
     ref = None
@@ -363,38 +344,13 @@ def test_quad_walk_equals_binary_walk(ctx, mesh, ns, depth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh,ns,depth,world", [("TorusKnot", 1, 4, 1), ("BlenderMonkey", 4, 3, 1), ("TorusKnot", 2, 4, 2)])
-def test_render_passes_graph_replay_equals_pass_by_pass(ctx, mesh, ns, depth, world):
-    """rtw_render_passes (UpdateBitmapPixels' sample loop: a captured launch graph replayed with the pass index on the
-    device) accumulates exactly what pass-by-pass rtw_render_tasks calls do, from any first pass, with the graph on or off."""
-    W, H = 640, 360
-    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.8, 0.9, 1.0)))
-    ctx.set_option("pipeline", 3)        # (the one-pass-per-set-of-launches pipeline; the pass-batched default has its own test below)
-    ref = R.Framebuffer(ctx, W, H)
-    for rank in range(world):
-        for p in range(3, 3 + 9):
-            s.render_tasks(ref, 10, rank, world, depth, None, p, ns, 77)
-    ra, rb = ref.read_float(), ref.resolve_argb()
-    for graph in (1, 0):
-        ctx.set_option("use_graph", graph)
-        fb = R.Framebuffer(ctx, W, H)
-        for rank in range(world):
-            s.render_passes(fb, 10, rank, world, depth, None, 3, 5, ns, 77)     # first call: plain passes, then the graph
-            s.render_passes(fb, 10, rank, world, depth, None, 8, 4, ns, 77)     # second call: continues the sequence
-        a, b = fb.read_float(), fb.resolve_argb()
-        assert (bits(a) == bits(ra)).all() and (b == rb).all(), graph
-    ctx.set_option("use_graph", 0)
-    ctx.set_option("pipeline", DEFAULT_PIPELINE)
-
-
-@pytest.mark.gpu
 def test_config5_shape_4k_depth8_pipelines_agree_and_tasks_compose(ctx):
     """BASELINE configs[4] at its full frame size (unitychan + textures, 3840x2160, depth 8; one 4-spp pass of the 16 spp):
-    the default bins + wave pipeline gives the bits of the packet / path-kernel pipeline, and the frame dealt as 10-row tasks
+    the pass-batched and the bins + wave pipelines give the bits of the single kernel, and the frame dealt as 10-row tasks
     over 8 ranks (rendered one after another into one buffer) equals the one-rank frame."""
     W, H = 3840, 2160
     s = gpu_scene(ctx, "unitychan", R.SurfaceMaterial_Diffuse((1, 1, 1)))
-    ctx.set_option("pipeline", 1)
+    ctx.set_option("pipeline", 0)
     a1, b1 = render_frame(ctx, s, W, H, 4, 8, 0, 2024, 3, 1)
     ctx.set_option("pipeline", 3)
     a3, b3 = render_frame(ctx, s, W, H, 4, 8, 0, 2024, 3, 1)
@@ -543,34 +499,10 @@ def test_scene_pipelines_agree_at_size(ctx, tag, W, H, ns, depth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh,W,H,depth,preview", [("TorusKnot", 1920, 1080, 4, 0), ("unitychan", 640, 360, 2, 0), ("BlenderMonkey", 800, 800, 9, 0),
-                                                    ("TorusKnot", 320, 180, 3, 1)])
-def test_single_sample_passes_resolved_by_the_shading_lanes_equal_the_resolve_kernel(ctx, mesh, W, H, depth, preview):
-    """With one sample per pixel the lane that ends a path accumulates and resolves its pixel itself and the pass has no resolve
-    launch (option resolve_inline, default on): same accumulator and ARGB bits as with the resolve kernel, over accumulated passes,
-    dealt tasks and graph replay."""
-    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5))
-    out = []
-    ctx.set_option("pipeline", 3)
-    for inline in (0, 1):
-        ctx.set_option("resolve_inline", inline)
-        a, b = render_frame(ctx, s, W, H, 1, depth, preview, 2468, 2, 3)
-        fb = R.Framebuffer(ctx, W, H)
-        for rank in range(2):
-            s.render_passes(fb, 10, rank, 2, depth, R.RenderOption(bool(preview)), 2, 3, 1, 2468)
-        out.append((a, b, fb.read_float(), fb.resolve_argb()))
-    ctx.set_option("resolve_inline", 1)
-    ctx.set_option("pipeline", DEFAULT_PIPELINE)
-    for k in range(4):
-        assert (bits(out[0][k]) == bits(out[1][k])).all(), k
-    assert (bits(out[1][0]) == bits(out[1][2])).all() and (out[1][1] == out[1][3]).all()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("mesh,ns,depth,world", [("TorusKnot", 1, 4, 1), ("unitychan", 4, 3, 2), ("BlenderMonkey", 2, 5, 3)])
 def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, mesh, ns, depth, world):
     """rtw_render_passes launches its passes as one run (the second stream, which renders the sky-only tiles, is forked before the
-    first pass and joined after the last; option batch_passes): same bits as one rtw_render_tasks call per pass, also when other
+    first pass and joined after the last): same bits as one rtw_render_tasks call per pass, also when other
     work follows the call at once (a read-back, another rank's run into the same buffer)."""
     W, H = 1280, 720
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.8, 1.0)))
@@ -580,39 +512,13 @@ def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, m
             s.render_tasks(ref, 10, rank, world, depth, None, p, ns, 99)
     ra, rb = ref.read_float(), ref.resolve_argb()
     ctx.set_option("pipeline", 3)
-    for batch in (1, 0):
-        ctx.set_option("batch_passes", batch)
-        fb = R.Framebuffer(ctx, W, H)
-        for rank in range(world):
-            s.render_passes(fb, 10, rank, world, depth, None, 0, 4, ns, 99)
-            s.render_passes(fb, 10, rank, world, depth, None, 4, 3, ns, 99)
-        a, b = fb.read_float(), fb.resolve_argb()
-        assert (bits(a) == bits(ra)).all() and (b == rb).all(), batch
-    ctx.set_option("batch_passes", 1)
+    fb = R.Framebuffer(ctx, W, H)
+    for rank in range(world):
+        s.render_passes(fb, 10, rank, world, depth, None, 0, 4, ns, 99)
+        s.render_passes(fb, 10, rank, world, depth, None, 4, 3, ns, 99)
+    a, b = fb.read_float(), fb.resolve_argb()
+    assert (bits(a) == bits(ra)).all() and (b == rb).all()
     ctx.set_option("pipeline", DEFAULT_PIPELINE)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4), ("BlenderMonkey", 3, 2), ("TorusKnot", 2, 9)])
-def test_last_trace_round_that_finishes_its_paths_equals_a_last_shade_launch(ctx, mesh, ns, depth):
-    """When no material of the scene emits, a path whose last segment hits gets exactly 0 and one whose last segment misses the sky
-    colour, whatever the hit's shading inputs: the last trace round can fold the levels itself (option finish_in_trace; off by default,
-    it measured slower).
-    Same bits as with the last shade launch; a scene with an Emissive node keeps that launch (and equals the single kernel)."""
-    W, H = 1280, 720
-    mats = [R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5),
-            R.SurfaceMaterial_Combine(R.SurfaceMaterial_Diffuse((0.8, 0.8, 0.8)), R.SurfaceMaterial_Emissive((0.2, 0.1, 0.05)))]
-    for mat in mats:
-        s = gpu_scene(ctx, mesh, mat)
-        out = []
-        for finish, pipeline in ((1, 3), (0, 3), (1, 0)):
-            ctx.set_option("finish_in_trace", finish)
-            ctx.set_option("pipeline", pipeline)
-            out.append(render_frame(ctx, s, W, H, ns, depth, 0, 1357, 0, 2))
-        ctx.set_option("finish_in_trace", 0)
-        ctx.set_option("pipeline", DEFAULT_PIPELINE)
-        for o in out[1:]:
-            assert (bits(out[0][0]) == bits(o[0])).all() and (out[0][1] == o[1]).all()
 
 
 # ---- the pass-batched pipeline (pipeline 4, the default): K passes share one set of launches ---------------------------------
@@ -728,14 +634,14 @@ def test_k_batched_passes_multi_shape_scenes(ctx, tag, W, H, ns, depth):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh,ns,depth", [("TorusKnot", 1, 4), ("unitychan", 4, 4)])
 def test_pass_batched_trace_variants_agree(ctx, mesh, ns, depth):
-    """The trace round's variants -- persistent waves that refill their lanes / plain batches, upper tree levels staged in LDS / read through
-    L2, a wave per ray for short lists, rays that exceed their visit budget handed to the wave-per-ray kernel -- give the same bits (1280x720, 5 passes)."""
+    """The trace round's variants -- a ray per lane in persistent waves that refill their lanes, a wave per ray for short lists, rays that exceed their
+    visit budget handed to the wave-per-ray kernel -- give the same bits (1280x720, 5 passes)."""
     W, H = 1280, 720
     s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Diffuse((0.9, 0.9, 0.8)))
     ref = None
     try:
-        for persist, stage, below, budget in ((1, 1, 100000, 256), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 8), (1, 1, 100000000, 256), (1, 1, 0, 64)):
-            for k, v in (("trace_persist", persist), ("trace_stage", stage), ("wave_below", below), ("visit_budget", budget)):
+        for below, budget in ((100000, 256), (0, 0), (0, 8), (100000000, 256), (0, 64)):
+            for k, v in (("wave_below", below), ("visit_budget", budget)):
                 ctx.set_option(k, v)
             fb = R.Framebuffer(ctx, W, H)
             s.render_passes(fb, 10, 0, 1, depth, None, 0, 5, ns, 2025)
@@ -745,9 +651,9 @@ def test_pass_batched_trace_variants_agree(ctx, mesh, ns, depth):
             if ref is None:
                 ref = out
             else:
-                assert (bits(out[0]) == bits(ref[0])).all() and (out[1] == ref[1]).all(), (persist, stage, below, budget)
+                assert (bits(out[0]) == bits(ref[0])).all() and (out[1] == ref[1]).all(), (below, budget)
     finally:
-        for k, v in (("trace_persist", 1), ("trace_stage", 1), ("wave_below", 80000), ("visit_budget", 384)):
+        for k, v in (("wave_below", 80000), ("visit_budget", 384)):
             ctx.set_option(k, v)
     ctx.set_option("pipeline", 0)
     a0, b0 = R.Framebuffer(ctx, W, H), None
@@ -834,7 +740,7 @@ def test_device_built_tree_equals_the_references(ctx, name):
         s.commit()
         b, skip, tri = s.mesh_nodes()
         assert (bits(b) == bits(g["tree_bounds"])).all() and (tri == g["tree_tri"]).all(), dev
-        out[dev] = dict(skip=skip, depth=s.mesh_info()["max_depth"], flat=[s.mesh_flat(l) for l in range(3)], quads=s.mesh_quads(),
+        out[dev] = dict(skip=skip, depth=s.mesh_info()["max_depth"], flat=[s.mesh_flat(l) for l in range(3)],
                         bins=s.mesh_bins(1920, 1080, 16, 4), bins2=s.mesh_bins(333, 217, 16, 4))
         s.close()
     ctx.set_option("device_build", 1)
@@ -842,7 +748,6 @@ def test_device_built_tree_equals_the_references(ctx, name):
     assert (d["skip"] == h["skip"]).all() and d["depth"] == h["depth"]
     for l in range(3):
         assert (bits(d["flat"][l]) == bits(h["flat"][l])).all(), l
-    assert (bits(d["quads"][0]) == bits(h["quads"][0])).all() and (d["quads"][1] == h["quads"][1]).all()
     for k in ("bins", "bins2"):
         assert (d[k][0] == h[k][0]).all() and (d[k][1] == h[k][1]).all()
 

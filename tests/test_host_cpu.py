@@ -142,36 +142,6 @@ def test_empty_mesh_and_ragged_inputs():
 
 
 @pytest.mark.parametrize("name", ["TorusKnot", "BlenderMonkey", "unitychan"])
-def test_quad_tree_is_an_order_preserving_collapse_of_the_reference_tree(name):
-    """Depth-first over the 4-wide tree, slots left to right, must meet the leaves in the binary tree's
-    preorder, each with the reference's own leaf box."""
-    g = np.load(os.path.join(GOLDEN, "mesh_%s.npz" % name))
-    s = R.RayTracerScene(None)
-    s.AddShape(R.RMeshShape.Create(asset(name + ".obj")))
-    b, c = s.mesh_quads()
-    EMPTY = -2 ** 31
-    order, boxes = [], []
-
-    def walk(q):
-        for k in range(4):
-            ch = int(c[q, k])
-            if ch == EMPTY:
-                continue
-            if ch < 0:
-                order.append(-1 - ch)
-                boxes.append(b[q, :, k])
-            else:
-                assert ch > q           # breadth-first numbering: children after parents
-                walk(ch)
-    import sys
-    sys.setrecursionlimit(10000)
-    walk(0)
-    leaf = g["tree_tri"] >= 0
-    assert order == g["tree_tri"][leaf].tolist()
-    assert (bits(np.array(boxes)) == bits(g["tree_bounds"][leaf])).all()
-
-
-@pytest.mark.parametrize("name", ["TorusKnot", "BlenderMonkey", "unitychan"])
 def test_flat_hierarchy_is_the_reference_leaves_in_preorder_under_unions(name):
     """Level 0 of the flat hierarchy = the reference tree's leaf boxes in preorder, bit for bit (the walk gives each
     leaf's OWN box the reference's test); every entry of level 1 / 2 is the exact union of its 16 children."""

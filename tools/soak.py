@@ -70,8 +70,7 @@ def material(rng, depth=0):
     return R.SurfaceMaterial_Null()
 
 
-DEFAULTS = dict(pipeline=4, direct_slots=1, sky_split=1, wave_stage=0, trace_block=128, use_graph=0, lead_split=1, resolve_inline=1, batch_passes=1,
-                finish_in_trace=0, auto_fused=1, group_max=256, trace_stage=1, trace_persist=1, wave_below=80000, visit_budget=384, group_split=1, split_min=8, split_paths=400000)
+DEFAULTS = dict(pipeline=4, group_max=256, wave_below=80000, visit_budget=384, group_split=1, split_min=8, split_paths=400000, workspace_limit_mb=0)
 
 
 def run(seed_arg, cases, ctx=None, log=print, only=-1, pipelines=(0, 3, 4), keep=None, override=None):
@@ -104,12 +103,11 @@ def run(seed_arg, cases, ctx=None, log=print, only=-1, pipelines=(0, 3, 4), keep
         spp, depth = int(rng.integers(1, 5)), int(rng.integers(0, 9))
         prev, seed, npass = int(rng.random() < 0.15), int(rng.integers(1, 1 << 30)), int(rng.integers(1, 9))
         world, rows = int(rng.choice([1, 1, 2, 3, 8])), int(rng.choice([10, 10, 7, 16, 1]))
-        opts = dict(direct_slots=int(rng.random() < 0.8), sky_split=int(rng.random() < 0.8), wave_stage=int(rng.choice([0, 0, 0, 1, 2, 3, -1])),
-                    trace_block=int(rng.choice([64, 128, 256])), use_graph=int(rng.random() < 0.3), lead_split=int(rng.random() < 0.8), resolve_inline=int(rng.random() < 0.8), batch_passes=int(rng.random() < 0.7), finish_in_trace=int(rng.random() < 0.4), auto_fused=int(rng.random() < 0.7))
-        # the pass-batched pipeline's own switches: passes per group, staging, persistent waves, the wave-per-ray threshold, the visit budget
-        gopts = dict(group_max=int(rng.choice([1, 2, 4, 64, 256])), trace_stage=int(rng.random() < 0.7), trace_persist=int(rng.random() < 0.7),
-                     wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 384])), sky_split=opts["sky_split"],
-                     group_split=int(rng.random() < 0.8), split_min=int(rng.choice([2, 2, 4, 8])), split_paths=int(rng.choice([0, 0, 400000])))
+        opts = dict(batch=int(rng.random() < 0.7))        # pipeline 3: its passes as one rtw_render_passes run, or call by call
+        # the pass-batched pipeline's switches: passes per group, the wave-per-ray threshold, the visit budget, split groups, a workspace limit that forces smaller groups
+        gopts = dict(group_max=int(rng.choice([1, 2, 4, 64, 256])), wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 384])),
+                     group_split=int(rng.random() < 0.8), split_min=int(rng.choice([2, 2, 4, 8])), split_paths=int(rng.choice([0, 0, 400000])),
+                     workspace_limit_mb=int(rng.choice([0, 0, 0, 1, 8])))
         if override:
             gopts.update(override)
         if only >= 0 and it != only:        # replay of one case: the others only advance the generator
@@ -120,13 +118,11 @@ def run(seed_arg, cases, ctx=None, log=print, only=-1, pipelines=(0, 3, 4), keep
         res = []
         for pl in pipelines:
             ctx.set_option("pipeline", pl)
-            for k, v in opts.items():
-                ctx.set_option(k, v if pl == 3 else DEFAULTS[k])
             for k, v in gopts.items():
                 ctx.set_option(k, v if pl == 4 else DEFAULTS[k])
             fb = R.Framebuffer(ctx, W, H)
             for rank in range(world):
-                if (pl == 3 and (opts["use_graph"] or opts["batch_passes"])) or (pl == 4 and rng.random() < 0.8):
+                if (pl == 3 and opts["batch"]) or (pl == 4 and rng.random() < 0.8):
                     s.render_passes(fb, rows, rank, world, depth, R.RenderOption(bool(prev)), 0, npass, spp, seed)
                 else:
                     for p in range(npass):
