@@ -18,7 +18,7 @@
 #include "rtw_device.h"
 
 #ifdef RTW_TIMING
-__device__ unsigned long long g_rtw_timing[6 * 16384];
+__device__ unsigned long long g_rtw_timing[12 * 16384];
 #endif
 
 namespace {

@@ -22,10 +22,11 @@
 //
 // Every float operation is the one the other pipelines execute, in the same order; the tests compare them bit for bit.
 
+// RTW_TIMING build (tools/wave_stats.py): per-wave clocks and lane-occupancy counters of the persistent trace kernel, filed in g_rtw_timing
 #ifdef RTW_TIMING
-#define RTW_GT_COUNT(x) (x)++
+#define RTW_TM(...) __VA_ARGS__
 #else
-#define RTW_GT_COUNT(x) (void)0
+#define RTW_TM(...)
 #endif
 #define RTW_GT_CAP 16           // candidate leaves a lane of gtrace_kernel notes before the wave runs its triangle tests (256-thread blocks, nothing staged)
 #ifndef RTW_GT_UNROLL
@@ -424,9 +425,6 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
                 block_push<4>(gb.tlist0, &gb.counters[24], (tqueued >> i) & 1u, group_slot(g, b, (uint32_t)lane, i, kpass), part);
         }
     }
-#ifdef RTW_TIMING
-    if ((threadIdx.x & 63u) == 0u) atomicMax(&g_rtw_timing[6 * 16000], wall_clock64());      // last wave of the primary kernel leaves
-#endif
     if (STATS) flush_counters(sc, ct);
 }
 
@@ -457,8 +455,7 @@ __device__ __forceinline__ LaneRay lane_ray_of(const Ray& r)
 // clip.  A wave that holds a ray that is not tame takes the loop that also evaluates the test as written.
 template <bool STATS, int NT, int CAP, bool ALLDS>
 __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* __restrict__ cand, const float4* __restrict__ lnodes, int ltop,
-                                               const Ray& r, const LaneRay& q, bool go, bool prune, float& cur, f3& pos, int& leaf_out, Counters& ct,
-                                               int& dbg_walk, int& dbg_tri, int& dbg_flush)
+                                               const Ray& r, const LaneRay& q, bool go, bool prune, float& cur, f3& pos, int& leaf_out, Counters& ct)
 {
     const float4* nd4 = reinterpret_cast<const float4*>(sh.tnodes);
     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
@@ -477,8 +474,7 @@ __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* 
         if (!any_untame) {
             for (;;) {
                 if (__ballot(i < n_nodes) == 0ull) break;
-                RTW_GT_COUNT(dbg_walk);
-#pragma unroll
+            #pragma unroll
                 for (int u = 0; u < RTW_GT_UNROLL; u++) {        // several visits between two looks at the wave (see gtrace_persist_kernel)
                 const bool walking = (i < n_nodes) & (ncand < CAP);
                 if (walking) {
@@ -503,8 +499,7 @@ __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* 
             for (;;) {
                 const bool walking = i < n_nodes;
                 if (__ballot(walking) == 0ull) break;
-                RTW_GT_COUNT(dbg_walk);
-                if (walking) {
+                            if (walking) {
                     float4 a, b;
                     if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
                     else { a = gld4(nd4, 2 * (size_t)i); b = gld4(nd4, 2 * (size_t)i + 1); }
@@ -535,9 +530,7 @@ __device__ __forceinline__ bool lane_mesh_walk(const RtwShapeDev& sh, uint32_t* 
             int leaf = mine ? (int)lldu(cand, tid) : 0;
             float4 ta = gld4(tr4, 4 * (size_t)leaf), tb = gld4(tr4, 4 * (size_t)leaf + 1), tc = gld4(tr4, 4 * (size_t)leaf + 2);
             float td = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)leaf + 12);
-            RTW_GT_COUNT(dbg_flush);
             for (int j = 0; __ballot(mine) != 0ull; j++) {
-                RTW_GT_COUNT(dbg_tri);
                 const bool nmine = j + 1 < ncand;
                 const int nleaf = nmine ? (int)lldu(cand, (j + 1) * NT + tid) : 0;
                 const float4 na = gld4(tr4, 4 * (size_t)nleaf), nb = gld4(tr4, 4 * (size_t)nleaf + 1), nc = gld4(tr4, 4 * (size_t)nleaf + 2);
@@ -561,8 +554,7 @@ template <bool STATS, bool AN, int NT, int CAP, bool ALLDS>
 __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __restrict__ sc, uint32_t* __restrict__ cand, const float4* __restrict__ lnodes, int ltop, int staged_shape,
                                                        const Ray& ray, bool have, int first_shape,
                                                        int& hit_shape, int& hit_slot, f3& hit_pos, float& seg,
-                                                       int& carry_shape, int& carry_slot, f3& carry_pos, float& carry_dist, Counters& ct,
-                                                       int& dbg_walk, int& dbg_tri, int& dbg_flush)
+                                                       int& carry_shape, int& carry_slot, f3& carry_pos, float& carry_dist, Counters& ct)
 {
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
@@ -581,8 +573,8 @@ __device__ __forceinline__ void lane_find_intersection(const RtwSceneDev* __rest
         if (AN && kind != RTW_SHAPE_MESH) {
             if (inbox) any = analytic_test(sh, ray, seg, pos, cur, slot);
         } else if (sh.n_nodes > 0) {
-            if (ALLDS && s == staged_shape) any = lane_mesh_walk<STATS, NT, CAP, true>(sh, cand, lnodes, ltop, ray, q, inbox, prune, cur, pos, slot, ct, dbg_walk, dbg_tri, dbg_flush);
-            else any = lane_mesh_walk<STATS, NT, CAP, false>(sh, cand, lnodes, s == staged_shape ? ltop : 0, ray, q, inbox, prune, cur, pos, slot, ct, dbg_walk, dbg_tri, dbg_flush);
+            if (ALLDS && s == staged_shape) any = lane_mesh_walk<STATS, NT, CAP, true>(sh, cand, lnodes, ltop, ray, q, inbox, prune, cur, pos, slot, ct);
+            else any = lane_mesh_walk<STATS, NT, CAP, false>(sh, cand, lnodes, s == staged_shape ? ltop : 0, ray, q, inbox, prune, cur, pos, slot, ct);
         }
         if (any) {
             seg = cur; hit_shape = s; hit_slot = slot; hit_pos = pos;
@@ -619,11 +611,6 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
     const uint32_t nthreads = gridDim.x * (uint32_t)NT;
     const uint32_t lane = (uint32_t)lane_id();
     Counters ct = { 0, 0, 0, 0, 0, 0 };
-    int dbg_walk = 0, dbg_tri = 0, dbg_flush = 0;
-#ifdef RTW_TIMING
-    const unsigned long long rtw_t0 = wall_clock64();
-    unsigned long long rtw_t1 = rtw_t0;
-#endif
     for (uint32_t base = blockIdx.x * (uint32_t)NT + (threadIdx.x & ~63u); base < n; base += nthreads) {     // wave-uniform
         const uint32_t k = base + lane;
         const bool have = k < n;
@@ -638,26 +625,13 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
             const float4 h0 = gb.hit[(size_t)slot * 2], h1 = gb.hit[(size_t)slot * 2 + 1];
             pos = mk(h0.x, h0.y, h0.z); seg = h0.w; hs = __float_as_int(h1.x); hslot = __float_as_int(h1.y);
         }
-#ifdef RTW_TIMING
-        rtw_t1 = wall_clock64();
-#endif
-        lane_find_intersection<STATS, AN, NT, CAP, (STAGE == 2)>(sc, cand, lnodes, ltop, STAGE ? staged_shape : -1, ray, have, AN ? lead : 0, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct,
-                                                                 dbg_walk, dbg_tri, dbg_flush);
+        lane_find_intersection<STATS, AN, NT, CAP, (STAGE == 2)>(sc, cand, lnodes, ltop, STAGE ? staged_shape : -1, ray, have, AN ? lead : 0, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct);
         if (have) {
             gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, seg);
             gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(cs), __int_as_float(cslot));
             if (AN && gb.carry_on) gb.carry[slot] = make_float4(cpos.x, cpos.y, cpos.z, cdist);
         }
     }
-#ifdef RTW_TIMING
-    {
-        const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63u) == 0 && w < 16384 && round == 0) {
-            g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = (unsigned long long)dbg_walk;
-            g_rtw_timing[6 * w + 3] = (unsigned long long)dbg_tri; g_rtw_timing[6 * w + 4] = (unsigned long long)dbg_flush; g_rtw_timing[6 * w + 5] = rtw_t1;
-        }
-    }
-#endif
     if (STATS) flush_counters(sc, ct);
 }
 
@@ -698,9 +672,7 @@ template <bool STATS, int NT, int CAP, int STAGE>
 __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
 {
     HIP_DYNAMIC_SHARED(uint32_t, gt_dyn);                 // [CAP * NT candidate words | staged records]
-#ifdef RTW_TIMING
-    const unsigned long long rtw_entry = wall_clock64();
-#endif
+    RTW_TM(const unsigned long long tm_entry = wall_clock64(); unsigned long long tm_walk = 0ull, tm_tri = 0ull, tm_refill = 0ull; uint32_t tm_wtrips = 0u, tm_wlanes = 0u, tm_ttrips = 0u, tm_tlanes = 0u, tm_events = 0u, tm_rays = 0u;)
     uint32_t* cand = gt_dyn;
     const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
     const RtwShapeDev& sh = sc->shapes[0];
@@ -749,14 +721,9 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         const uint32_t k = batch_entry<SPREAD>(batch, n_batches, n, st_count);
         if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
     }
-#ifdef RTW_TIMING
-    int dbg_walk = 0, dbg_tri = 0, dbg_ev = 0; unsigned long long dbg_refill = 0ull;
-    const unsigned long long rtw_t0 = wall_clock64();
-#endif
+    RTW_TM(const unsigned long long tm_start = __builtin_amdgcn_s_memtime();)
     for (;;) {
-#ifdef RTW_TIMING
-        const unsigned long long rtw_e0 = wall_clock64(); dbg_ev++;
-#endif
+        RTW_TM(const unsigned long long tm_e0 = __builtin_amdgcn_s_memtime(); tm_events++;)
         // ---- hand the idle lanes new rays, out of the 64 the wave fetched ahead (lane e of the staging registers holds entry e) ----
         if (st_used < st_count) {
             const unsigned long long idle = __ballot(!have);
@@ -784,6 +751,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     i = slab_exact(r, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1) ? 0 : n_nodes;
                 }
                 st_used += take;
+                RTW_TM(tm_rays += take;)
                 if (st_used == st_count) {          // fetch the next 64 now: they arrive while the wave walks
                     uint32_t batch;
                     if (DRAW) {
@@ -801,9 +769,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
             }
         }
         const bool exhausted = st_used >= st_count;
-#ifdef RTW_TIMING
-        dbg_refill += wall_clock64() - rtw_e0;
-#endif
+        RTW_TM(const unsigned long long tm_e1 = __builtin_amdgcn_s_memtime(); tm_refill += tm_e1 - tm_e0;)
         if (__ballot(have) == 0ull) break;
         const bool any_untame = __ballot(have && !tame) != 0ull;
         const float far_t = prune ? cur + (eps_t + 1.0e-4f * cur) : INFINITY;
@@ -814,12 +780,12 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
             const rtw_v2f vx = { ix, ix }, vy = { iy, iy }, vz = { iz, iz };
             for (;;) {
                 if (__ballot(have & (i < n_nodes)) == 0ull) break;
-                RTW_GT_COUNT(dbg_walk);
-                // RTW_GT_UNROLL visits between two looks at the wave (the three ballots, their scalar compares and branches: a CU has ONE scalar
+                            // RTW_GT_UNROLL visits between two looks at the wave (the three ballots, their scalar compares and branches: a CU has ONE scalar
                 // unit for its sixteen waves); a lane whose list is full sits the extra visits out, its sequence of visits is the same
 #pragma unroll
                 for (int u = 0; u < RTW_GT_UNROLL; u++) {
                 const bool walking = have & (i < n_nodes) & (ncand < CAP);
+                RTW_TM(tm_wtrips++; tm_wlanes += (uint32_t)__popcll(__ballot(walking));)
                 if (walking) {
                     float4 a, b;
                     if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
@@ -844,8 +810,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
             for (;;) {
                 const bool walking = have & (i < n_nodes);
                 if (__ballot(walking) == 0ull) break;
-                RTW_GT_COUNT(dbg_walk);
-                if (walking) {
+                            if (walking) {
                     float4 a, b;
                     if (ALLDS || i < ltop) { a = lld4(lnodes, 2 * i); b = lld4(lnodes, 2 * i + 1); }
                     else { a = gld4(nd4, 2 * (size_t)i); b = gld4(nd4, 2 * (size_t)i + 1); }
@@ -871,6 +836,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                 if (!exhausted && __popcll(__ballot(have & (i >= n_nodes))) >= RTW_GT_REFILL) break;
             }
         }
+        RTW_TM(const unsigned long long tm_e2 = __builtin_amdgcn_s_memtime(); tm_walk += tm_e2 - tm_e1;)
         // ---- a ray that has used up its budget of node visits leaves for the wave-per-ray kernel that follows (it starts over there:
         // a whole wave on one ray shortens the chain of dependent steps that would otherwise keep this launch waiting) ----
         {
@@ -894,7 +860,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
             float4 ta = gld4(tr4, 4 * (size_t)leaf), tb = gld4(tr4, 4 * (size_t)leaf + 1), tc = gld4(tr4, 4 * (size_t)leaf + 2);
             float td = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)leaf + 12);
             for (int j = 0; __ballot(mine) != 0ull; j++) {
-                RTW_GT_COUNT(dbg_tri);
+                RTW_TM(tm_ttrips++; tm_tlanes += (uint32_t)__popcll(__ballot(mine));)
                 const bool nmine = j + 1 < ncand;
                 const int nleaf = nmine ? (int)lldu(cand, (j + 1) * NT + tid) : 0;
                 const float4 na = gld4(tr4, 4 * (size_t)nleaf), nb = gld4(tr4, 4 * (size_t)nleaf + 1), nc = gld4(tr4, 4 * (size_t)nleaf + 2);
@@ -915,13 +881,15 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
             gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(leaf_out), __int_as_float(-1), __int_as_float(-1));
             have = false;
         }
+        RTW_TM(tm_tri += __builtin_amdgcn_s_memtime() - tm_e2;)
     }
 #ifdef RTW_TIMING
     {
         const unsigned w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63u) == 0 && w < 16384 && round == 0) {
-            g_rtw_timing[6 * w] = rtw_t0; g_rtw_timing[6 * w + 1] = wall_clock64(); g_rtw_timing[6 * w + 2] = (unsigned long long)dbg_walk;
-            g_rtw_timing[6 * w + 3] = (unsigned long long)dbg_tri; g_rtw_timing[6 * w + 4] = (unsigned long long)dbg_ev; g_rtw_timing[6 * w + 5] = rtw_entry;
+        if ((threadIdx.x & 63u) == 0 && w < 16384 && round == RTW_TIMING) {        // -DRTW_TIMING=<round + 0>: which trace round files its waves
+            unsigned long long* o = &g_rtw_timing[12 * w];
+            o[0] = tm_entry; o[1] = wall_clock64(); o[2] = tm_wtrips; o[3] = tm_wlanes; o[4] = tm_ttrips; o[5] = tm_tlanes; o[6] = tm_events; o[7] = tm_walk; o[8] = tm_tri; o[9] = tm_refill;
+            o[10] = tm_rays; o[11] = __builtin_amdgcn_s_memtime() - tm_start;
         }
     }
 #endif
@@ -982,9 +950,6 @@ __global__ __launch_bounds__(256, RTW_GSHADE_MINB) void gshade_kernel(const RtwS
     const uint32_t phase = table_phase(p.seed);
     const uint32_t kmask = (1u << g.kshift) - 1u;
     __shared__ uint32_t part[5];
-#ifdef RTW_TIMING
-    if (round == 1 && g.first_pass == 2 * g.n_passes && (threadIdx.x & 63u) == 0u) atomicMax(&g_rtw_timing[6 * 16000 + 1], 0x7FFFFFFFFFFFFFFFull - wall_clock64());     // first wave of shade(1) enters
-#endif
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     const uint32_t trips = (n + nthreads - 1) / nthreads;        // grid-uniform trip count: every thread joins the pushes
     for (uint32_t it = 0, k = blockIdx.x * blockDim.x + threadIdx.x; it < trips; it++, k += nthreads) {

@@ -146,6 +146,7 @@ struct rtw_context {
     int last_pipeline = -1;             // the pipeline the latest render call actually ran (rtw_last_pass_pipeline)
     size_t workspace_limit = (size_t)24 << 30;  // a group's workspace may not exceed this (option "workspace_limit_mb"); hipMalloc failing counts as exceeding it
     bool ws_refused = false;            // the latest ensure_group_workspace was refused (limit or out of memory): the caller retries with a smaller group
+    bool ws_single = false;             // the group at hand is one pass: the limit does not apply (only hipMalloc can refuse it)
     int group_cap = 0;                  // > 0: groups of the current rtw_render_passes call hold at most this many passes (set after a refusal)
     int fallbacks = 0;                  // how many times a group was re-formed smaller after a refusal (rtw_context_memory_bytes' caller can see it: option-free diagnostics)
 };
@@ -1116,7 +1117,7 @@ static int ensure_group_workspace(rtw_context* cx, size_t bytes)
     size_t& have = cx->lane ? cx->group_ws2_bytes : cx->group_ws_bytes;
     cx->ws_refused = false;
     if (bytes <= have) return RTW_OK;
-    if (bytes > cx->workspace_limit) { cx->ws_refused = true; return fail(RTW_ERR_HIP, "group workspace above the context's workspace limit"); }
+    if (bytes > cx->workspace_limit && !cx->ws_single) { cx->ws_refused = true; return fail(RTW_ERR_HIP, "group workspace above the context's workspace limit"); }      // (a one-pass group is always tried: the limit shapes groups, it does not refuse frames)
     // grow-only; growing waits for the streams (rtw_render_reserve does it ahead of a call that must not stall)
     HIP_TRY(hipStreamSynchronize(cx->stream));
     if (cx->aux_stream) HIP_TRY(hipStreamSynchronize(cx->aux_stream));
@@ -1240,7 +1241,10 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
     if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");
     // the workspace of THIS group (grow-only): a caller that must not stall inside a later, longer call reserves it with rtw_render_reserve
-    rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr)); if (rc != RTW_OK) return rc;
+    cx->ws_single = n_passes == 1 && cx->lane == 0 && cx->lane_sky_passes == 0;
+    rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr));
+    cx->ws_single = false;
+    if (rc != RTW_OK) return rc;
     rtw::GroupTuning tune;
     tune.capacity = capacity;
     tune.aux_stream = cx->aux_stream; tune.fork_event = cx->fork_event; tune.join_event = cx->join_event;
