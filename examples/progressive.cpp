@@ -22,6 +22,8 @@ static void OnFrame(void* user, const Pixel* px, int w, int h)
     s->checksum = sum;
 }
 static void OnTitle(void* user, const char*) { ((Seen*)user)->titles++; }
+// RTW_EXAMPLE_DEVICE_SINK=1: the window takes the image where it lies, in device memory (an interop surface / encoder would read it there): no host copy per present
+static void OnDeviceFrame(void* user, const void* device_pixels, int, int) { if (device_pixels) ((Seen*)user)->frames++; }
 
 int main(int argc, char** argv)
 {
@@ -39,6 +41,8 @@ int main(int argc, char** argv)
         Window.Create(W, H);
         Window.SetRenderBufferParameters(W, H, Shown.data());
         Window.SetSinks(OnFrame, OnTitle, &seen);
+        const bool DeviceSink = std::getenv("RTW_EXAMPLE_DEVICE_SINK") != nullptr;
+        if (DeviceSink) Window.SetDeviceSink(OnDeviceFrame, &seen);
         RtwProgressive Run;
         Run.TotalSamplesNum = TotalSamplesNum; Run.MaxBounceTimes = MaxBounceTimes; Run.Window = &Window;
         Run.PassesPerUpdate = argc > 7 ? std::atoi(argv[7]) : 1;
@@ -61,7 +65,12 @@ int main(int argc, char** argv)
             Run.Comm = Comm;
             if (Run.Rank != 0) { Run.Window = nullptr; Run.Quiet = true; }
         }
+        if (std::getenv("RTW_EXAMPLE_QUIET")) Run.Quiet = true;
+        const std::chrono::steady_clock::time_point T0 = std::chrono::steady_clock::now();
         const std::string Saved = UpdateBitmapPixels(Device, Scene, Buffer, Run);
+        const double TotalMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
+        if (Run.Rank == 0) std::printf("loop: %.3f ms for %d passes, %d per update: %.4f ms per update end to end (render + synchronise + title + present%s)\n", TotalMs, TotalSamplesNum,
+                                       Run.PassesPerUpdate, TotalMs / ((TotalSamplesNum + Run.PassesPerUpdate - 1) / Run.PassesPerUpdate + 1), DeviceSink ? " of the device image" : " through the host buffer");
         if (Comm) RtwCheck(rtw_comm_destroy(Comm));
         if (Run.Rank != 0) return 0;
         Window.RunWindowLoop();
@@ -71,7 +80,7 @@ int main(int argc, char** argv)
             unsigned long long sum = 0;
             for (size_t i = 0; i < bitcolor.size(); i++) sum += bitcolor[i] & 0xFFFFFFu;
             std::printf("window: %d frames presented, %d titles, last frame %s the final image; title: %s\n", seen.frames, seen.titles,
-                        sum == seen.checksum ? "equals" : "DIFFERS FROM", Window.GetTitle().c_str());
+                        DeviceSink ? "stayed on the device, not compared with" : (sum == seen.checksum ? "equals" : "DIFFERS FROM"), Window.GetTitle().c_str());
         }
         std::printf("saved: %s\n", Saved.c_str());
     } catch (const RtwFailure& e) {

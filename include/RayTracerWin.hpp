@@ -294,20 +294,27 @@ public:
 // The reference blits bitcolor[] to a native window and writes the progress line into its title.  On a headless GPU node the same
 // four calls feed a SINK: every presented frame (the resolved 0xAARRGGBB image) and every title go to callbacks, if set, and are
 // counted.  SetRenderBufferParameters names the caller's pixel buffer exactly like the reference's call (width, height, buffer);
-// the renderer copies the device image into it before each Present().
+// the renderer copies the device image into it before each Present().  A sink that can take the image where it lies -- a device pointer (an interop
+// surface, an encoder, a kernel of the caller's) -- sets a DEVICE sink instead: it is called with the device address of the 0xAARRGGBB image after every
+// update, the renders that produced it already complete, and no host copy is made at all (8.3 MB per present at 1080p otherwise).
 class RenderWindow {
 public:
     typedef void (*FrameSink)(void* User, const Pixel* Pixels, int Width, int Height);
+    typedef void (*DeviceFrameSink)(void* User, const void* DevicePixels, int Width, int Height);
     typedef void (*TitleSink)(void* User, const char* Title);
-    RenderWindow() : Width(0), Height(0), Buffer(nullptr), OnFrame(nullptr), OnTitle(nullptr), User(nullptr), Frames(0), Created(false), Closing(false) {}
+    RenderWindow() : Width(0), Height(0), Buffer(nullptr), OnFrame(nullptr), OnDeviceFrame(nullptr), OnTitle(nullptr), User(nullptr), Frames(0), Created(false), Closing(false) {}
     bool Create(int InWidth, int InHeight) { if (InWidth <= 0 || InHeight <= 0) return false; Width = InWidth; Height = InHeight; Created = true; return true; }
     void SetRenderBufferParameters(int BufferWidth, int BufferHeight, void* InBuffer) { Width = BufferWidth; Height = BufferHeight; Buffer = (Pixel*)InBuffer; }
     void SetTitle(const char* InTitle) { Title = InTitle ? InTitle : ""; if (OnTitle) OnTitle(User, Title.c_str()); }
     // the reference's loop pumps native events until the window closes; a sink has no events: it returns once the renderer is done
     void RunWindowLoop() { Closing = true; }
     void SetSinks(FrameSink InFrame, TitleSink InTitle, void* InUser) { OnFrame = InFrame; OnTitle = InTitle; User = InUser; }
+    void SetDeviceSink(DeviceFrameSink InFrame, void* InUser) { OnDeviceFrame = InFrame; User = InUser; }
+    bool WantsDeviceFrames() const { return OnDeviceFrame != nullptr; }
     // called by the renderer after the buffer named in SetRenderBufferParameters has been refreshed
     void Present() { Frames++; if (OnFrame && Buffer) OnFrame(User, Buffer, Width, Height); }
+    // ... or with the image still in device memory (no host buffer involved)
+    void PresentDevice(const void* DevicePixels, int W, int H) { Frames++; if (OnDeviceFrame) OnDeviceFrame(User, DevicePixels, W, H); }
     Pixel* RenderBuffer() const { return Buffer; }
     int BufferWidth() const { return Width; }
     int BufferHeight() const { return Height; }
@@ -315,7 +322,7 @@ public:
     int PresentedFrames() const { return Frames; }
     bool IsCreated() const { return Created; }
 private:
-    int Width, Height; Pixel* Buffer; FrameSink OnFrame; TitleSink OnTitle; void* User; std::string Title; int Frames; bool Created, Closing;
+    int Width, Height; Pixel* Buffer; FrameSink OnFrame; DeviceFrameSink OnDeviceFrame; TitleSink OnTitle; void* User; std::string Title; int Frames; bool Created, Closing;
 };
 
 // ---- Src/RayTracerProgram.cpp:242-268 ----------------------------------------------------------------------------------------------
@@ -342,7 +349,7 @@ struct RtwProgressive {
     int PassesPerUpdate;        // passes rendered between two progress lines / presents: 1 = the reference's rhythm; more lets the library
                                 // batch the passes of an update into shared launches (several times faster on small frames)
     uint32_t Seed;
-    const volatile bool* bQuit; // polled after every update (RayTracerProgram::IsTerminating)
+    const volatile bool* bQuit; // polled after every update (RayTracerProgram::IsTerminating); with several ranks rank 0's flag decides for all of them
     RenderWindow* Window;       // display hook, may be null
     int Rank, World;            // this process renders the 10-row tasks t with t % World == Rank ...
     rtw_comm* Comm;             // ... and the rows travel to rank 0 over RCCL before every present and before the image is saved (null with World == 1)
@@ -358,11 +365,17 @@ inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, 
     using Clock = std::chrono::system_clock;
     const int TaskRows = 10;                       // NumTaskRows
     const bool Root = Run.Rank == 0;
+    if (Run.World > 1 && !Run.Comm) throw std::invalid_argument("UpdateBitmapPixels: several ranks need a communicator (RtwProgressive::Comm): without the gather rank 0 would show and save its own rows only");
     auto Show = [&](const char* Text) {            // gather (several ranks), refresh the window's buffer, present
-        if (Run.World > 1 && Run.Comm) RtwCheck(rtw_gather_rows(Run.Comm, Buffer.Get(), TaskRows, Run.ArgbOnlyGather ? RTW_GATHER_ARGB : RTW_GATHER_ALL));
+        if (Run.World > 1) RtwCheck(rtw_gather_rows(Run.Comm, Buffer.Get(), TaskRows, Run.ArgbOnlyGather ? RTW_GATHER_ARGB : RTW_GATHER_ALL));
         if (!Root || !Run.Window) return;
         if (Text) Run.Window->SetTitle(Text);
-        if (Run.Window->RenderBuffer() && Run.Window->BufferWidth() == Buffer.bitmapWidth() && Run.Window->BufferHeight() == Buffer.bitmapHeight()) {
+        if (Run.Window->WantsDeviceFrames()) {     // the image where it lies: no host copy
+            void* DeviceArgb = nullptr;
+            RtwCheck(rtw_framebuffer_device_pointers(Buffer.Get(), nullptr, &DeviceArgb));
+            Device.Synchronize();
+            Run.Window->PresentDevice(DeviceArgb, Buffer.bitmapWidth(), Buffer.bitmapHeight());
+        } else if (Run.Window->RenderBuffer() && Run.Window->BufferWidth() == Buffer.bitmapWidth() && Run.Window->BufferHeight() == Buffer.bitmapHeight()) {
             RtwCheck(rtw_framebuffer_resolve_argb(Buffer.Get(), Run.Window->RenderBuffer()));
             Run.Window->Present();
         }
@@ -374,6 +387,7 @@ inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, 
     const Clock::time_point Begin = Clock::now();
     Clock::time_point Previous = Begin;
     const int Step = Run.PassesPerUpdate > 0 ? Run.PassesPerUpdate : 1;
+    RtwCheck(rtw_render_reserve(Scene.Get(), Buffer.Get(), TaskRows, Run.Rank, Run.World, Run.MaxBounceTimes, Step, 4));      // the updates' workspace, once, outside the loop
     int Rendered = 0;
     while (Rendered < Run.TotalSamplesNum) {
         const int Count = Run.TotalSamplesNum - Rendered < Step ? Run.TotalSamplesNum - Rendered : Step;
@@ -391,7 +405,9 @@ inline std::string UpdateBitmapPixels(RtwDevice& Device, RayTracerScene& Scene, 
         std::snprintf(Line, sizeof Line, "RayTracer - S: [%d/%d] | T: [%s / %s] | F: [%dms]", Rendered, Run.TotalSamplesNum, Spent, Remaining, SinceUpdate);
         if (Root && !Run.Quiet) std::printf("%s\n", Line);
         Show(Line);
-        if (Run.bQuit && *Run.bQuit) break;
+        int Quit = (Run.bQuit && *Run.bQuit) ? 1 : 0;
+        if (Run.World > 1) RtwCheck(rtw_comm_broadcast_int(Run.Comm, &Quit));      // rank 0 decides for every rank: one that left alone would leave the others in the next gather
+        if (Quit) break;
     }
     // (every update's Show() has gathered, the last one after the last pass: rank 0 holds the whole image here.  The gather is a collective of the
     // ranks: it must never depend on something only one rank has, such as a window)

@@ -87,7 +87,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   (the one-pass reference the pass-batched pipeline is compared with); 0 = one kernel, one thread per pixel (with
  *                   rtw_scene_set_traversal(0): the reference's own visit order, for the work counters).
  *   "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold; "group_split" (1) a group of at least
- *                   "split_min" (8) passes and 2 x "split_paths" (400 000) paths runs as two halves on two streams (a second workspace of the same size);
+ *                   "split_min" (8) passes runs as up to "group_parts" (2; at most 4) parts of at least "split_paths" (400 000) paths each, on as many streams
+ *                   (a workspace per part);
  *   "wave_below" (80 000; x 5 for trees of more than 4 096 nodes) a trace round with fewer rays runs a wave per ray; "visit_budget" (384) one-mesh scenes:
  *                   a ray's node visits in the ray-per-lane kernel before it goes to the wave-per-ray one (a rare ray that walks a thousand nodes kept its
  *                   whole wave waiting), for trees with more than "budget_nodes" (0) nodes;
@@ -187,6 +188,10 @@ int rtw_framebuffer_clear(rtw_framebuffer* fb);
 /* copy out: accum4 = width*height*4 floats (sum.xyz, count as float); argb = 0xAARRGGBB */
 int rtw_framebuffer_read_float(rtw_framebuffer* fb, float* accum4);
 int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb);
+/* the device addresses of the two arrays (accum: width*height float4 = sum.xyz + int count; argb: width*height 0xAARRGGBB words), e.g. for a display
+ * hook that blits bitcolor[] straight out of device memory (Src/Windows/RenderWindow.cpp:150-187 blits the host array); valid while the framebuffer
+ * lives; order reads after the renders on the context's stream.  Either pointer argument may be NULL. */
+int rtw_framebuffer_device_pointers(rtw_framebuffer* fb, void** accum_dev, void** argb_dev);
 
 /* ---- the hot path ---- */
 /* ThreadWorker_Render(begin, end, MaxBounceCount, RenderOption{use_base_color})
@@ -250,6 +255,9 @@ int rtw_comm_destroy(rtw_comm* comm);
 int rtw_gather_rows(rtw_comm* comm, rtw_framebuffer* fb, int task_rows, int mode);
 /* ncclSend / ncclRecv operations this communicator has issued so far (a gather costs a sender one, the root world - 1) */
 long long rtw_comm_messages(const rtw_comm* comm);
+/* rank 0's *value to every rank (a decision every rank must take alike, e.g. RayTracerProgram::IsTerminating polled on rank 0: a rank that left the
+ * progressive loop alone would leave the others blocked in the next gather).  Synchronous; every rank of the communicator must call it. */
+int rtw_comm_broadcast_int(rtw_comm* comm, int* value);
 
 /* work counters of launches since the last reset (only counted while enabled) */
 int rtw_stats_enable(rtw_context* ctx, int enabled);

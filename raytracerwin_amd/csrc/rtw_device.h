@@ -54,9 +54,11 @@ struct GroupTuning {
     int round_hint[32];            // list lengths of the previous group per round (-1 = unknown): they size the launches
     int cu_count = 256;
     bool single_mesh = false;      // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
-    // a group rendered as two halves on two streams (rtwin_capi.cpp: render_passes): the first half's sky kernel takes the passes of both,
-    // the second half launches none and its resolve kernel waits for the first half's
-    int sky_passes = 0; bool no_sky = false; hipEvent_t resolve_after = nullptr;
+    bool lead_mesh = false;        // ... or leading analytic shapes followed by ONE mesh (shape staged_shape), no texel inheritance: the same kernel, continuing the lead query
+    // a group rendered as several parts on as many streams (rtwin_capi.cpp: rtw_render_passes): part sky_part of sky_parts renders its share of the group's
+    // sky tiles for ALL the group's passes (sky_first_pass, sky_passes) on its own stream; its resolve kernel waits for the previous part's (resolve_after)
+    // and signals the next (resolve_done)
+    int sky_passes = 0, sky_first_pass = 0, sky_part = 0, sky_parts = 1; hipEvent_t resolve_after = nullptr, resolve_done = nullptr;
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
     int trace_hint[32];                      // scenes with leading analytic shapes: how many rays of a round still went to the trace launch (previous group)
     bool skip_trace = false;                 // every shape is a leading analytic shape: the shading lanes do the whole query, no trace launches

@@ -825,30 +825,6 @@ __device__ __forceinline__ uint32_t pack_pixel(const float* __restrict__ thr, f3
     return (255u << 24) | (gamma_fix(thr, c.x, gx, x0, x1) << 16) | (gamma_fix(thr, c.y, gy, y0, y1) << 8) | gamma_fix(thr, c.z, gz, z0, z1);
 }
 
-// pack_pixel for a pixel whose previous pass's bytes are known (the sky kernel keeps a pixel in registers for all passes of a group): an
-// averaged colour moves by less than a threshold step from one pass to the next, so the bracket [thr[k], thr[k + 1]) of the previous byte usually
-// still holds -- two compares instead of log2 / exp2 and two table reads; when it does not, the walk from the old k is a step or two.
-// The value is gamma_channel's in every case: 0 for !(c > 0) (NaN too), 255 for c >= 1, else the largest k with thr[k] <= c.
-struct GammaBracket { int k; float t0, t1; };      // k < 0: nothing cached yet
-__device__ __forceinline__ uint32_t gamma_bracketed(const float* __restrict__ thr, float c, GammaBracket& g)
-{
-    if (!(g.t0 <= c && c < g.t1)) {
-        int k = g.k < 0 ? gamma_guess(c) : g.k;
-        if (!(c > 0.0f)) k = 0;
-        else if (c >= 1.0f) k = 255;
-        else {
-            while (k < 255 && thr[k + 1] <= c) k++;
-            while (k > 0 && thr[k] > c) k--;
-        }
-        g.k = k; g.t0 = thr[k]; g.t1 = k < 255 ? thr[k + 1] : __int_as_float(0x7F800000);
-    }
-    return (uint32_t)g.k;
-}
-__device__ __forceinline__ uint32_t pack_pixel_bracketed(const float* __restrict__ thr, f3 c, GammaBracket* g)
-{
-    return (255u << 24) | (gamma_bracketed(thr, c.x, g[0]) << 16) | (gamma_bracketed(thr, c.y, g[1]) << 8) | gamma_bracketed(thr, c.z, g[2]);
-}
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1428,9 +1404,18 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     gb.capacity = (uint32_t)tune.capacity; gb.carry_on = tune.carry ? 1 : 0;
     if (!tune.counters_clean) { hipError_t e = hipMemsetAsync(gb.counters, 0, 256, stream); if (e != hipSuccess) return (int)e; }
     bool forked = false;
-    if (g.n_sky > 0 && !tune.no_sky) {
+    if (g.n_sky > 0 && tune.sky_parts > 1) {
+        // a part of a split group: its share of the sky tiles, all the group's passes, first kernel of this part's stream
+        const int s0 = (int)((long long)g.n_sky * tune.sky_part / tune.sky_parts), s1 = (int)((long long)g.n_sky * (tune.sky_part + 1) / tune.sky_parts);
+        if (s1 > s0) {
+            RtwGroupParams gs = g;
+            gs.sky_tiles = g.sky_tiles + s0; gs.n_sky = s1 - s0; gs.first_pass = tune.sky_first_pass; gs.n_passes = tune.sky_passes;
+            int sgrid = (gs.n_sky + 3) / 4;
+            if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
+            hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, gs);
+        }
+    } else if (g.n_sky > 0) {
         RtwGroupParams gs = g;
-        if (tune.sky_passes > 0) gs.n_passes = tune.sky_passes;
         hipStream_t ss = stream;
         if (tune.aux_stream) {
             forked = !tune.do_fork || (hipEventRecord(tune.fork_event, stream) == hipSuccess && hipStreamWaitEvent(tune.aux_stream, tune.fork_event, 0) == hipSuccess);
@@ -1503,15 +1488,16 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
                         else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 0, p.lead_shapes);
                     }
-                } else if (tune.single_mesh && tune.staged_shape == 0 && tune.staged_top > 0) {
+                } else if ((tune.single_mesh || tune.lead_mesh) && tune.staged_top > 0) {
                     // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
-#define RTW_LAUNCH_GP(NT_, CAP_, STG, BLOCKS, DYN)                                                                                               \
+#define RTW_LAUNCH_GPL(NT_, CAP_, STG, LD, BLOCKS, DYN)                                                                                          \
                     do {                                                                                                                        \
-                        if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget); } \
-                        else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget); } \
+                        if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG, LD>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget, tune.staged_shape); } \
+                        else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG, LD>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget, tune.staged_shape); } \
                     } while (0)
+#define RTW_LAUNCH_GP(NT_, CAP_, STG, BLOCKS, DYN) do { if (tune.lead_mesh) RTW_LAUNCH_GPL(NT_, CAP_, STG, true, BLOCKS, DYN); else RTW_LAUNCH_GPL(NT_, CAP_, STG, false, BLOCKS, DYN); } while (0)
                     {
                         unsigned sbl = (tb + 3) / 4;
                         if (sbl > (unsigned)tune.cu_count) sbl = (unsigned)tune.cu_count;
@@ -1520,6 +1506,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         else RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 1, sbl, dyn);
                     }
 #undef RTW_LAUNCH_GP
+#undef RTW_LAUNCH_GPL
                     if (tune.visit_budget < INT32_MAX) {        // the rays that ran out of budget: a wave each
                         constexpr int NTV = 128;
                         // a generous grid: the count varies from group to group, a wave-per-ray loop with too few waves is slow (measured: 0.9 ms for a few
@@ -1529,8 +1516,13 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                         const long long cap = (long long)tune.cu_count * 64;
                         if (blocks > cap) blocks = cap;
                         const size_t dyn = (size_t)(NTV / 64) * RTW_WAVE_LDS_WORDS * 4;
-                        if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, 0);
-                        else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, 0);
+                        if (tune.lead_mesh) {
+                            if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, p.lead_shapes);
+                            else hipLaunchKernelGGL((gtrace_wave_kernel<false, true, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, p.lead_shapes);
+                        } else {
+                            if (stats) hipLaunchKernelGGL((gtrace_wave_kernel<true, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, 0);
+                            else hipLaunchKernelGGL((gtrace_wave_kernel<false, false, NTV>), dim3((unsigned)blocks), dim3(NTV), dyn, stream, sc, gb, r - 1, 1, 0);
+                        }
                     }
                 } else if (tune.staged_shape >= 0 && tune.staged_top > 0) {
                     const unsigned sbl = (tb + 3) / 4;          // 1024-thread blocks
@@ -1556,6 +1548,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
         if (tune.timing) (void)hipEventRecord(tune.timing[2], stream);
         if (tune.resolve_after) (void)hipStreamWaitEvent(stream, tune.resolve_after, 0);      // a pixel's passes are added in pass order
         hipLaunchKernelGGL(gresolve_kernel, dim3((unsigned)((g.n_busy + 3) / 4)), dim3(256), 0, stream, sc, (float4*)accum, (uint32_t*)argb, gb, g);
+        if (tune.resolve_done) (void)hipEventRecord(tune.resolve_done, stream);
     } else if (tune.timing) {
         (void)hipEventRecord(tune.timing[1], stream); (void)hipEventRecord(tune.timing[2], stream);
     }
@@ -1601,8 +1594,12 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
     RTW_HIP_OK(hipMemcpyAsync(d_in, in.idx_n, (size_t)n * 12, hipMemcpyHostToDevice, stream));
     RTW_HIP_OK(hipMemcpyAsync(d_mat, in.tri_material, (size_t)n * 4, hipMemcpyHostToDevice, stream));
     BUILD_MARK("temps + uploads");
-    // outputs (owned by the caller afterwards)
+    // outputs (owned by the caller afterwards; an early return frees what was allocated so far)
     DeviceBuildOut o; std::memset(&o, 0, sizeof o);
+    struct OutGuard {
+        DeviceBuildOut* o; bool keep = false;
+        ~OutGuard() { if (!keep) { (void)hipFree(o->nodes); (void)hipFree(o->tnodes); (void)hipFree(o->tris); (void)hipFree(o->shade); for (int l = 0; l < 3; l++) (void)hipFree(o->flat[l]); } }
+    } guard{ &o };
     o.n_nodes = n_nodes;
     RTW_HIP_OK(hipMalloc((void**)&o.nodes, (size_t)n_nodes * sizeof(RtwNode)));
     RTW_HIP_OK(hipMalloc((void**)&o.tnodes, (size_t)n_nodes * sizeof(RtwPNode)));
@@ -1670,6 +1667,7 @@ int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* o
     BUILD_MARK("derived layouts");
     o.tnodes_top = D < 0 ? 0 : ntop;
     *out = o;
+    guard.keep = true;
     return 0;
 }
 // Screen bins of one mesh on the device.  *off_out (n_bins + 1 offsets) and *ent_out are the caller's (hipFree); h_off receives the offsets

@@ -3,11 +3,12 @@
 //
 // The passes of the reference's sample loop (UpdateBitmapPixels, Src/RayTracerProgram.cpp:317-361) are independent apart from the
 // order in which a pixel's pass colours are added to its accumulator (AccumulatePixel::AddPixel, :51-75).  A GROUP of K consecutive
-// passes therefore shares one set of launches -- K times the rays per launch, 1 / K of the launches -- and every pixel's
-// accumulate + gamma + ARGB pack still runs once per pass, in pass order:
+// passes therefore shares one set of launches -- K times the rays per launch, 1 / K of the launches.  A pixel's pass colours are added to its
+// accumulator one by one in pass order (the same float additions as pass-by-pass calls); its accumulator entry and its ARGB word are WRITTEN once per
+// group (the ARGB word = GetGammaSpacePixel after the group's last pass): the images between the passes of a group are not materialised.
 //
 //   gsky_kernel      sky-only tiles (no leaf of any shape can be met from them): one lane per pixel, the K passes in a row with the
-//                    accumulator entry in registers (read once, written once per group), ARGB stored every pass.  Second stream.
+//                    accumulator entry in registers (read once, written once per group); the ARGB word is resolved once, after the group's last pass.
 //   gprimary_kernel  one wave per (busy tile, pass[, sub-sample]): the camera rays through the tile's screen bin -- the bins walk of
 //                    primary_bins_kernel -- and the first shading step.  A path that ends writes its radiance, one that goes on saves
 //                    its state in its slot and joins round 0's ray list (ONE atomic per wave).
@@ -18,7 +19,7 @@
 //                    with the segment left by the previous accepted hit -- the reference's sequence (Src/KdTree.cpp:128-195).
 //   gshade_kernel    one lane per path: RayTrace's per-hit block (Src/RayTracerScene.cpp:47-94).
 //   gresolve_kernel  one lane per pixel of the busy tiles: for each pass of the group in order, the pass colour from the samples'
-//                    radiances, AddPixel, GetGammaSpacePixel, ARGB store.
+//                    radiances and AddPixel; then GetGammaSpacePixel and the ARGB store, once.
 //
 // Every float operation is the one the other pipelines execute, in the same order; the tests compare them bit for bit.
 
@@ -218,8 +219,7 @@ __global__ __launch_bounds__(256) void gsky_kernel(const float* __restrict__ gam
         if (!p.preview) acc = accum[pixel];
         f3 sum = mk(acc.x, acc.y, acc.z);
         int n = __float_as_int(acc.w);
-        GammaBracket gb3[3];
-        for (int c = 0; c < 3; c++) { gb3[c].k = -1; gb3[c].t0 = 1.0f; gb3[c].t1 = 0.0f; }       // an empty bracket: the first pass looks its bytes up
+        f3 c = mk(0, 0, 0);
         for (int k = 0; k < g.n_passes; k++) {
             f3 csum = mk(0, 0, 0);
             for (int i = 0; i < p.sub_samples; i++) {
@@ -228,12 +228,12 @@ __global__ __launch_bounds__(256) void gsky_kernel(const float* __restrict__ gam
                 const f3 si = p.max_bounce != 0 ? sky_color(ray.d.y) : mk(0, 0, 0);       // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
                 csum = csum + si;
             }
-            const f3 c = p.sub_samples == 1 ? csum : csum / (float)p.sub_samples;          // x / 1.0f == x
-            uint32_t packed;
-            if (p.preview) packed = pack_pixel_bracketed(thr, c, gb3);
-            else { sum = sum + c; n++; packed = pack_pixel_bracketed(thr, n == 1 ? sum : sum / (float)n, gb3); }
-            __builtin_nontemporal_store(packed, &argb[pixel]);      // bitcolor[] is written every pass (Src/RayTracerProgram.cpp:185)
+            c = p.sub_samples == 1 ? csum : csum / (float)p.sub_samples;                   // x / 1.0f == x
+            if (!p.preview) { sum = sum + c; n++; }                                        // AccumulatePixel::AddPixel, pass after pass in pass order
         }
+        // bitcolor[] as it stands after the group's LAST pass: GetGammaSpacePixel of the accumulator (a preview pass shows its own colour).  The images
+        // the reference would show BETWEEN the passes of a group are not materialised: nothing can look at them inside one call.
+        argb[pixel] = pack_pixel(thr, p.preview ? c : (n == 1 ? sum : sum / (float)n));
         if (!p.preview) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
     }
 }
@@ -668,14 +668,18 @@ __device__ __forceinline__ uint32_t batch_entry(uint32_t batch, uint32_t n_batch
 #ifndef RTW_GT_REFILL
 #define RTW_GT_REFILL 16
 #endif
-template <bool STATS, int NT, int CAP, int STAGE>
-__global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget)
+// LEAD: the scene is `ms` leading spheres / planes / capsules / triangles followed by this ONE mesh (the reference's default scene): the lane that set
+// the segment up has tested the leading shapes (group_lead_query); the list is the rays that can still meet the mesh's box, their hit records hold the
+// query so far, and the mesh's hits are measured against the segment those shapes left.
+template <bool STATS, int NT, int CAP, int STAGE, bool LEAD>
+__global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget, int ms)
 {
     HIP_DYNAMIC_SHARED(uint32_t, gt_dyn);                 // [CAP * NT candidate words | staged records]
     RTW_TM(const unsigned long long tm_entry = wall_clock64(); unsigned long long tm_walk = 0ull, tm_tri = 0ull, tm_refill = 0ull; uint32_t tm_wtrips = 0u, tm_wlanes = 0u, tm_ttrips = 0u, tm_tlanes = 0u, tm_events = 0u, tm_rays = 0u;)
     uint32_t* cand = gt_dyn;
-    const uint32_t n = gb.counters[round] < gb.capacity ? gb.counters[round] : gb.capacity;
-    const RtwShapeDev& sh = sc->shapes[0];
+    const uint32_t nl = LEAD ? gb.counters[24 + round] : gb.counters[round];
+    const uint32_t n = nl < gb.capacity ? nl : gb.capacity;
+    const RtwShapeDev& sh = sc->shapes[LEAD ? ms : 0];
     const float4* lnodes = nullptr; int ltop = 0;
     // Who takes which 64-entry batch of the list.  A tree that lives in LDS entirely (STAGE 2: the config meshes TorusKnot and BlenderMonkey):
     // static, wave w of the grid takes batches w, w + waves, ... -- neighbouring batches (neighbours on the screen) on neighbouring waves.
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
     const int n_nodes = sh.n_nodes;
     const bool prune = sc->prune != 0;
-    const uint32_t* __restrict__ src = round & 1 ? gb.list1 : gb.list0;
+    const uint32_t* __restrict__ src = LEAD ? (round & 1 ? gb.tlist1 : gb.tlist0) : (round & 1 ? gb.list1 : gb.list0);
     const int tid = (int)threadIdx.x;
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     // the lane's ray and the state of its walk
@@ -709,6 +713,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
     float ix = 0.0f, iy = 0.0f, iz = 0.0f, eps_t = 0.0f, cur = 0.0f;
     f3 pos = mk(0, 0, 0);
     int i = n_nodes, leaf_out = -1, ncand = 0, visits = 0;
+    int lead_hs = -1, lead_slot = -1;       // LEAD: what the leading shapes' tests left (shape, part); the mesh's hit, if any, replaces it
     // the wave's share of the list: every nw-th batch of 64 entries (neighbouring entries come from neighbouring pixels and cost alike:
     // contiguous shares were measured 2 x out of balance), fetched one batch ahead into staging registers
     uint32_t st_count, st_used = 0u, st_slot = 0u;
@@ -747,6 +752,10 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     ix = (!tame && skx) ? 0.0f : 1.0f / r.d.x; iy = (!tame && sky) ? 0.0f : 1.0f / r.d.y; iz = (!tame && skz) ? 0.0f : 1.0f / r.d.z;
                     eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
                     cur = r.dist; pos = mk(0, 0, 0); leaf_out = -1; ncand = 0; visits = 0;
+                    if (LEAD) {         // FindIntersectionWithScene so far (Src/RayTracerScene.cpp:99-125): the segment is already shortened by the leading shapes' hits
+                        const float4 h0 = gb.hit[(size_t)slot * 2], h1 = gb.hit[(size_t)slot * 2 + 1];
+                        pos = mk(h0.x, h0.y, h0.z); cur = h0.w; lead_hs = __float_as_int(h1.x); lead_slot = __float_as_int(h1.y);
+                    }
                     float t0, t1;       // the shape's culling box (Src/RayTracerScene.cpp:109)
                     i = slab_exact(r, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1) ? 0 : n_nodes;
                 }
@@ -849,6 +858,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                 if (over) {
                     gb.overflow[base + (uint32_t)mbcnt(om)] = slot;
                     if (STATS) ct.rays--;        // the query is counted by the kernel that takes it over (the box / triangle tests run so far were run)
+                    // (LEAD: the hit record still holds the leading shapes' result; the wave-per-ray kernel continues from it)
                     have = false; ncand = 0; i = n_nodes;
                 }
             }
@@ -876,9 +886,9 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         }
         // ---- lanes whose walk is complete: FindIntersectionWithScene's result for the one shape ----
         if (have & (i >= n_nodes)) {
-            const int hs = leaf_out >= 0 ? 0 : -1;
+            const int hs = leaf_out >= 0 ? (LEAD ? ms : 0) : (LEAD ? lead_hs : -1);
             gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, cur);
-            gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(leaf_out), __int_as_float(-1), __int_as_float(-1));
+            gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(leaf_out >= 0 ? leaf_out : (LEAD ? lead_slot : -1)), __int_as_float(-1), __int_as_float(-1));
             have = false;
         }
         RTW_TM(tm_tri += __builtin_amdgcn_s_memtime() - tm_e2;)
@@ -1009,18 +1019,17 @@ __global__ __launch_bounds__(256) void gresolve_kernel(const RtwSceneDev* __rest
             if (!p.preview) acc = accum[pixel];
             f3 sum = mk(acc.x, acc.y, acc.z);
             int n = __float_as_int(acc.w);
+            f3 c = mk(0, 0, 0);
             for (int k = 0; k < g.n_passes; k++) {
-                f3 c = mk(0, 0, 0);
+                c = mk(0, 0, 0);
                 for (int i = 0; i < p.sub_samples; i++) {
                     const float4 r = gb.rad[group_slot(g, b, lane, (uint32_t)i, (uint32_t)k)];
                     c = c + mk(r.x, r.y, r.z);
                 }
                 c = c / (float)p.sub_samples;
-                uint32_t packed;
-                if (p.preview) packed = pack_pixel(thr, c);
-                else { sum = sum + c; n++; packed = pack_pixel(thr, n == 1 ? sum : sum / (float)n); }     // AddPixel + GetGammaSpacePixel
-                __builtin_nontemporal_store(packed, &argb[pixel]);
+                if (!p.preview) { sum = sum + c; n++; }                                    // AddPixel, in pass order
             }
+            argb[pixel] = pack_pixel(thr, p.preview ? c : (n == 1 ? sum : sum / (float)n));       // GetGammaSpacePixel after the group's last pass (see gsky_kernel)
             if (!p.preview) accum[pixel] = make_float4(sum.x, sum.y, sum.z, __int_as_float(n));
         }
     }

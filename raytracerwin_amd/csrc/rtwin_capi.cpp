@@ -82,6 +82,7 @@ void release_device_table(int device)
 
 }  // namespace
 
+#define RTW_MAX_PARTS 4
 struct rtw_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -114,18 +115,16 @@ struct rtw_context {
     int kernel_timing = 0;              // 1: record events around the three kernels of each pass
     hipEvent_t timing_events[4] = { nullptr, nullptr, nullptr, nullptr };
     // pass-batched pipeline (pipeline 4): its own workspace (the list counters sit at its start and are left zeroed by every group)
-    void* d_group_ws = nullptr;
-    size_t group_ws_bytes = 0;
-    bool group_clean = false;
-    // a group as two halves on two streams: the second half's stream, workspace and the events that order the halves
-    hipStream_t stream2 = nullptr;
-    void* d_group_ws2 = nullptr;
-    size_t group_ws2_bytes = 0;
-    bool group_clean2 = false;
-    hipEvent_t split_fork = nullptr, split_mid = nullptr, split_join = nullptr;
+    // a group runs as up to RTW_MAX_PARTS parts on as many streams (part 0 on the context's stream), each with its own workspace; the events order them
+    void* d_group_ws[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };
+    size_t group_ws_bytes[RTW_MAX_PARTS] = { 0, 0, 0, 0 };
+    bool group_clean[RTW_MAX_PARTS] = { false, false, false, false };
+    hipStream_t part_stream[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };        // [0] unused: part 0 runs on `stream`
+    hipEvent_t split_fork = nullptr, part_resolved[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr }, part_done[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };
+    int group_parts = 2;                      // option: parts a split group runs as, at most (measured on C2 / C4 at 20 passes: 2 parts -8 % / -1 % against one, 3 and 4 parts +10..25 %)
     int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes ...
     int split_paths = 400000;                 // ... and each half at least this many paths (a rank's share of a small frame at 8 ranks stays whole: measured 0.0123 whole, 0.0144 ms split)
-    int lane = 0, lane_sky_passes = 0;        // set by rtw_render_passes around render_group
+    int lane = 0, lane_count = 1, lane_sky_passes = 0, lane_sky_first = 0;        // set by rtw_render_passes around render_group: which part of how many; the whole group's passes (the parts share out its sky tiles)
     uint32_t* h_gcounters = nullptr;    // pinned: list lengths of a finished group
     hipEvent_t gcounters_event = nullptr;
     bool gcounters_pending = false;
@@ -247,10 +246,12 @@ int rtw_context_create(int device_index, rtw_context** out)
     HIP_TRY(hipMemcpy(c->d_gamma, thr, sizeof thr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->split_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->split_mid, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->split_join, hipEventDisableTiming));
+    for (int j = 0; j < RTW_MAX_PARTS; j++) {
+        if (j > 0) HIP_TRY(hipStreamCreateWithFlags(&c->part_stream[j], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->part_resolved[j], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->part_done[j], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault));
@@ -280,12 +281,13 @@ int rtw_context_destroy(rtw_context* ctx)
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
-    if (ctx->d_group_ws) (void)hipFree(ctx->d_group_ws);
-    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
-    if (ctx->d_group_ws2) (void)hipFree(ctx->d_group_ws2);
+    for (int j = 0; j < RTW_MAX_PARTS; j++) {
+        if (ctx->part_stream[j]) { (void)hipStreamSynchronize(ctx->part_stream[j]); (void)hipStreamDestroy(ctx->part_stream[j]); }
+        if (ctx->d_group_ws[j]) (void)hipFree(ctx->d_group_ws[j]);
+        if (ctx->part_resolved[j]) (void)hipEventDestroy(ctx->part_resolved[j]);
+        if (ctx->part_done[j]) (void)hipEventDestroy(ctx->part_done[j]);
+    }
     if (ctx->split_fork) (void)hipEventDestroy(ctx->split_fork);
-    if (ctx->split_mid) (void)hipEventDestroy(ctx->split_mid);
-    if (ctx->split_join) (void)hipEventDestroy(ctx->split_join);
     if (ctx->h_gcounters) (void)hipHostFree(ctx->h_gcounters);
     if (ctx->gcounters_event) (void)hipEventDestroy(ctx->gcounters_event);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -314,6 +316,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "workspace_limit_mb") == 0) { ctx->workspace_limit = value <= 0 ? ((size_t)24 << 30) : ((size_t)value << 20); return RTW_OK; }
+    if (std::strcmp(name, "group_parts") == 0) { ctx->group_parts = value < 1 ? 1 : (value > RTW_MAX_PARTS ? RTW_MAX_PARTS : value); return RTW_OK; }
     if (std::strcmp(name, "group_split") == 0) { ctx->group_split = value != 0; return RTW_OK; }
     if (std::strcmp(name, "split_paths") == 0) { ctx->split_paths = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "split_min") == 0) { ctx->split_min = value < 2 ? 2 : value; return RTW_OK; }
@@ -603,8 +606,9 @@ int rtw_scene_commit(rtw_scene* scene)
             // KdNode::Build's recursion and the layouts derived from the tree run on the device (rtw_build_kernels.h); the host keeps copies of
             // the small arrays for the screen bins, the older pipelines' collapsed trees and the inspection calls
             rtw::DeviceBuildIn in;
-            in.points = &m.points[0].x; in.n_points = (int)m.points.size(); in.texcoords = &m.texcoords[0].x; in.n_texcoords = (int)m.texcoords.size();
-            in.normals = &m.normals[0].x; in.n_normals = (int)m.normals.size();
+            in.points = reinterpret_cast<const float*>(m.points.data()); in.n_points = (int)m.points.size();       // (.data(): an OBJ without vt / vn lines has empty arrays)
+            in.texcoords = reinterpret_cast<const float*>(m.texcoords.data()); in.n_texcoords = (int)m.texcoords.size();
+            in.normals = reinterpret_cast<const float*>(m.normals.data()); in.n_normals = (int)m.normals.size();
             in.idx_p = m.point_idx.data(); in.idx_t = m.texcoord_idx.data(); in.idx_n = m.normal_idx.data(); in.tri_material = m.poly_material.data(); in.n_tris = m.n_tris();
             rtw::DeviceBuildOut o;
             const hipError_t be = (hipError_t)rtw::device_build_mesh(in, RTW_TNODES_TOP_BUDGET, &o, scene->ctx->stream);
@@ -747,8 +751,9 @@ int rtw_scene_mesh_bins(const rtw_scene* scene, int shape, int width, int height
         ok = has != 0;
         if (ok) {
             ent.resize(off.back() ? off.back() : 1, 0u);
-            if (off.back()) HIP_TRY(hipMemcpy(ent.data(), d_ent, (size_t)off.back() * 4, hipMemcpyDeviceToHost));
+            const hipError_t ce = off.back() ? hipMemcpy(ent.data(), d_ent, (size_t)off.back() * 4, hipMemcpyDeviceToHost) : hipSuccess;
             (void)hipFree(d_off); (void)hipFree(d_ent);
+            if (ce != hipSuccess) return hip_fail(ce, "bins read-back");
         }
     } else {
         ok = rtw::build_bins(*scene->meshes[(size_t)shape], width, height, bin_w, bin_h, off, ent);
@@ -910,6 +915,14 @@ int rtw_framebuffer_resolve_argb(rtw_framebuffer* fb, uint32_t* argb)
     const size_t n = (size_t)fb->width * (size_t)fb->height;
     HIP_TRY(hipMemcpyAsync(argb, fb->argb, n * 4, hipMemcpyDeviceToHost, fb->ctx->stream));
     HIP_TRY(hipStreamSynchronize(fb->ctx->stream));
+    return RTW_OK;
+}
+
+int rtw_framebuffer_device_pointers(rtw_framebuffer* fb, void** accum_dev, void** argb_dev)
+{
+    if (!fb) return fail(RTW_ERR_INVALID, "framebuffer is null");
+    if (accum_dev) *accum_dev = fb->accum;
+    if (argb_dev) *argb_dev = fb->argb;
     return RTW_OK;
 }
 
@@ -1113,17 +1126,17 @@ static int scene_group_table(rtw_scene* scene, rtw_scene::BinSet& bs, const RtwR
 
 static int ensure_group_workspace(rtw_context* cx, size_t bytes)
 {
-    void*& ws = cx->lane ? cx->d_group_ws2 : cx->d_group_ws;
-    size_t& have = cx->lane ? cx->group_ws2_bytes : cx->group_ws_bytes;
+    void*& ws = cx->d_group_ws[cx->lane];
+    size_t& have = cx->group_ws_bytes[cx->lane];
     cx->ws_refused = false;
     if (bytes <= have) return RTW_OK;
     if (bytes > cx->workspace_limit && !cx->ws_single) { cx->ws_refused = true; return fail(RTW_ERR_HIP, "group workspace above the context's workspace limit"); }      // (a one-pass group is always tried: the limit shapes groups, it does not refuse frames)
     // grow-only; growing waits for the streams (rtw_render_reserve does it ahead of a call that must not stall)
     HIP_TRY(hipStreamSynchronize(cx->stream));
     if (cx->aux_stream) HIP_TRY(hipStreamSynchronize(cx->aux_stream));
-    if (cx->stream2) HIP_TRY(hipStreamSynchronize(cx->stream2));
+    for (int j = 1; j < RTW_MAX_PARTS; j++) if (cx->part_stream[j]) HIP_TRY(hipStreamSynchronize(cx->part_stream[j]));
     if (ws) { (void)hipFree(ws); ws = nullptr; have = 0; }
-    (cx->lane ? cx->group_clean2 : cx->group_clean) = false;
+    cx->group_clean[cx->lane] = false;
     const hipError_t e = hipMalloc(&ws, bytes);
     if (e != hipSuccess) {      // no room on the device (a GPU shared with torch, other ranks ...): the caller forms a smaller group
         ws = nullptr; (void)hipGetLastError();
@@ -1166,13 +1179,18 @@ static int group_passes(const rtw_context* cx, long long paths_per_pass, int rem
 
 // The next group of a call: how many of the `remaining` passes it takes (the policy above, under the cap a refusal of workspace has set) and whether it
 // runs as two halves on two streams.
-static int next_group(const rtw_context* cx, long long per_pass, int remaining, int max_bounce, bool carry, bool preview, bool* split)
+static int next_group(const rtw_context* cx, long long per_pass, int remaining, int max_bounce, bool carry, bool preview, int* parts)
 {
-    *split = false;
+    *parts = 1;
     if (preview) return 1;
     int k = group_passes(cx, per_pass > 0 ? per_pass : 1, remaining, max_bounce, carry);
     if (cx->group_cap > 0 && k > cx->group_cap) k = cx->group_cap;
-    *split = cx->group_split && k >= cx->split_min && per_pass * (k / 2) >= cx->split_paths && !cx->stats_enabled && !cx->kernel_timing && cx->stream2 != nullptr;
+    if (cx->group_split && k >= cx->split_min && !cx->stats_enabled && !cx->kernel_timing) {
+        // as many parts as the option allows, each with at least split_min / 2 passes and split_paths paths
+        int n = cx->group_parts;
+        while (n > 1 && (k / n < (cx->split_min + 1) / 2 || per_pass * (k / n) < cx->split_paths)) n--;
+        *parts = n;
+    }
     return k;
 }
 
@@ -1241,7 +1259,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
     if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");
     // the workspace of THIS group (grow-only): a caller that must not stall inside a later, longer call reserves it with rtw_render_reserve
-    cx->ws_single = n_passes == 1 && cx->lane == 0 && cx->lane_sky_passes == 0;
+    cx->ws_single = n_passes == 1 && cx->lane_count == 1;
     rc = ensure_group_workspace(cx, rtw::group_workspace_bytes(capacity, max_bounce, carry, nullptr));
     cx->ws_single = false;
     if (rc != RTW_OK) return rc;
@@ -1252,18 +1270,30 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.do_join = cx->batch_pos == 0 || cx->batch_pos == 3; tune.aux_unjoined = &cx->aux_unjoined;
     tune.gamma_thr = cx->d_gamma;
     tune.has_analytic = scene->has_analytic; tune.carry = carry;
-    tune.counters_clean = cx->lane ? cx->group_clean2 : cx->group_clean;
-    if (cx->lane == 0) tune.sky_passes = cx->lane_sky_passes;
-    else { tune.no_sky = true; tune.resolve_after = cx->split_mid; tune.aux_stream = nullptr; }
+    tune.counters_clean = cx->group_clean[cx->lane];
+    if (cx->lane_count > 1) {       // a part of a split group: its share of the group's sky tiles (all the group's passes) on its own stream; its resolve kernel after the previous part's
+        tune.sky_passes = cx->lane_sky_passes; tune.sky_first_pass = cx->lane_sky_first;
+        tune.sky_part = cx->lane; tune.sky_parts = cx->lane_count;
+        tune.aux_stream = nullptr;
+        tune.resolve_after = cx->lane > 0 ? cx->part_resolved[cx->lane - 1] : nullptr;
+        tune.resolve_done = cx->part_resolved[cx->lane];
+    }
     tune.cu_count = cx->cu_count;
     {      // the first mesh's upper tree levels live in the trace blocks' LDS
         for (size_t k = 0; k < scene->meshes.size(); k++)
             if (scene->meshes[k]->kind == RTW_SHAPE_MESH && scene->meshes[k]->tnodes_top > 0) { tune.staged_shape = (int)k; tune.staged_top = scene->meshes[k]->tnodes_top; tune.staged_all = tune.staged_top == (int)scene->meshes[k]->tnodes.size(); break; }
     }
     tune.single_mesh = scene->meshes.size() == 1 && scene->meshes[0]->kind == RTW_SHAPE_MESH && !scene->meshes[0]->nodes.empty();
+    tune.lead_mesh = !carry && p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size() - 1 && scene->meshes.back()->kind == RTW_SHAPE_MESH && !scene->meshes.back()->nodes.empty() &&
+                     tune.staged_shape == p.lead_shapes;
+
     // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
-    tune.visit_budget = (cx->visit_budget > 0 && tune.single_mesh && scene->meshes[0]->nodes.size() > (size_t)cx->budget_nodes) ? cx->visit_budget : INT32_MAX;
-    tune.wave_below = (!scene->meshes.empty() && scene->meshes[0]->nodes.size() > 4096) ? cx->wave_below * 5 : cx->wave_below;     // long walks: the wave-per-ray kernel pays up to longer lists
+    tune.visit_budget = (cx->visit_budget > 0 && (tune.single_mesh || tune.lead_mesh) && scene->meshes.back()->nodes.size() > (size_t)cx->budget_nodes) ? cx->visit_budget : INT32_MAX;
+    {   // long walks (a tree of more than 4 096 nodes): the wave-per-ray kernel pays up to longer lists
+        bool big = false;
+        for (const auto& m : scene->meshes) if (m->nodes.size() > 4096) big = true;
+        tune.wave_below = big ? cx->wave_below * 5 : cx->wave_below;
+    }
     tune.timing = (cx->kernel_timing && cx->lane == 0) ? cx->timing_events : nullptr;
     // list lengths of the latest finished group with the same shape (a stale or missing value only costs speed)
     // (keyed by the launch shape WITHOUT the number of passes: the lengths are kept per pass and scaled to the group at hand, so a warm-up call of any
@@ -1282,16 +1312,16 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     for (int r = 0; r < 16; r++) tune.overflow_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_goverflow[r]) : -1;
     for (int r = 0; r < 16; r++) tune.trace_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_gtrace[r]) : -1;
     tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();
-    bool& clean = cx->lane ? cx->group_clean2 : cx->group_clean;
+    bool& clean = cx->group_clean[cx->lane];
     clean = false;
-    const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->lane ? cx->d_group_ws2 : cx->d_group_ws, g, tune, cx->stats_enabled,
-                                                              cx->lane ? cx->stream2 : cx->stream);
+    const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws[cx->lane], g, tune, cx->stats_enabled,
+                                                              cx->lane ? cx->part_stream[cx->lane] : cx->stream);
     if (e != hipSuccess) return hip_fail(e, "group launch");
     clean = true;
     cx->last_pipeline = 4;
-    cx->last_group_passes = cx->lane_sky_passes > 0 ? cx->lane_sky_passes : n_passes;
+    cx->last_group_passes = cx->lane_count > 1 ? cx->lane_sky_passes : n_passes;
     if (cx->lane == 0 && !cx->gcounters_pending && g.n_busy > 0 && (!(cx->known_gkey == key) || (cx->hint_tick++ % cx->hint_period) == 0)) {
-        if (hipMemcpyAsync(cx->h_gcounters, (char*)cx->d_group_ws + 256, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
+        if (hipMemcpyAsync(cx->h_gcounters, (char*)cx->d_group_ws[0] + 256, 256, hipMemcpyDeviceToHost, cx->stream) == hipSuccess &&
             hipEventRecord(cx->gcounters_event, cx->stream) == hipSuccess) {
             cx->gcounters_pending = true; cx->gcounters_key = key; cx->gcounters_passes = n_passes;
         }
@@ -1437,40 +1467,39 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
         cx->group_cap = 0;
         int done = 0;
         while (done < n_passes) {
-            bool split = false;
-            const int k = next_group(cx, per_pass, n_passes - done, max_bounce, scene->texture_carry, use_base_color != 0, &split);
+            int parts = 1;
+            const int k = next_group(cx, per_pass, n_passes - done, max_bounce, scene->texture_carry, use_base_color != 0, &parts);
+            const bool split = parts > 1;
             const bool first = done == 0, last = done + k >= n_passes;
             cx->batch_pos = (first && last) ? 0 : (first ? 1 : (last ? 3 : 2));
             if (split) {
-                // The group as two halves on two streams.  Its kernels are bound by latency, not by a throughput roof: one half's short
-                // rounds and launch tails overlap the other's long ones.  Order kept: the sky kernel (second stream) takes all k passes of its pixels in a
-                // row; the second half's resolve kernel waits for the first half's, so a busy tile's passes are added in pass order.
-                const int ka = k / 2, kb = k - ka;
-                // both halves' workspaces before anything of the group is launched: a refusal then leaves nothing half done
-                {
-                    RtwRenderParams t = p; t.width = fb->width; t.height = fb->height;
-                    size_t need = 0;
-                    if (choose_group_tiles(t, 0, last_pixel)) {
-                        int ks = 0; while ((1 << ks) < kb) ks++;
-                        need = rtw::group_workspace_bytes((size_t)per_pass << ks, max_bounce, scene->texture_carry, nullptr);
-                    }
-                    cx->lane = 0; rc = ensure_group_workspace(cx, need);
-                    if (rc == RTW_OK) { cx->lane = 1; rc = ensure_group_workspace(cx, need); }
+                // The group as `parts` parts on as many streams.  Its kernels are bound by latency, not by a throughput roof: every stage of a
+                // part's chain of launches lasts about as long as its longest ray, whatever the number of rays, so several shorter chains side by side use
+                // the chip where one long chain leaves it idle.  Order kept: a part's share of the sky tiles gets all k passes of its pixels in a row
+                // (first kernel of the part's stream); a part's resolve kernel waits for the previous part's, so a busy tile's passes are added in pass order.
+                const int base = k / parts, rem = k % parts;
+                {   // every part's workspace before anything of the group is launched: a refusal then leaves nothing half done
+                    int ks = 0; while ((1 << ks) < base + (rem ? 1 : 0)) ks++;
+                    const size_t need = rtw::group_workspace_bytes((size_t)per_pass << ks, max_bounce, scene->texture_carry, nullptr);
+                    for (int j = 0; j < parts && rc == RTW_OK; j++) { cx->lane = j; rc = ensure_group_workspace(cx, need); }
                     cx->lane = 0;
                 }
                 if (rc == RTW_OK) {
                     (void)hipEventRecord(cx->split_fork, cx->stream);
-                    (void)hipStreamWaitEvent(cx->stream2, cx->split_fork, 0);
-                    cx->lane = 0; cx->lane_sky_passes = k;
-                    rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, ka, sub_samples, seed);
-                    (void)hipEventRecord(cx->split_mid, cx->stream);
-                    if (rc == RTW_OK) {
-                        cx->lane = 1;
-                        rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done + ka, kb, sub_samples, seed);
+                    for (int j = 1; j < parts; j++) (void)hipStreamWaitEvent(cx->part_stream[j], cx->split_fork, 0);
+                    int off = 0;
+                    cx->lane_count = parts; cx->lane_sky_passes = k; cx->lane_sky_first = first_pass + done;
+                    for (int j = 0; j < parts && rc == RTW_OK; j++) {
+                        const int kj = base + (j < rem ? 1 : 0);
+                        cx->lane = j;
+                        rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done + off, kj, sub_samples, seed);
+                        off += kj;
                     }
-                    cx->lane = 0; cx->lane_sky_passes = 0;
-                    (void)hipEventRecord(cx->split_join, cx->stream2);
-                    (void)hipStreamWaitEvent(cx->stream, cx->split_join, 0);
+                    cx->lane = 0; cx->lane_count = 1; cx->lane_sky_passes = 0;
+                    for (int j = 1; j < parts; j++) {
+                        (void)hipEventRecord(cx->part_done[j], cx->part_stream[j]);
+                        (void)hipStreamWaitEvent(cx->stream, cx->part_done[j], 0);
+                    }
                 }
             } else
                 rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);
@@ -1479,7 +1508,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                 // no room for this group's workspace (the context's limit, or the device is full): nothing of the group has been launched -- form smaller
                 // groups for the rest of the call instead of failing (k = 1 needs ~300-600 bytes per path of one pass)
                 cx->ws_refused = false;
-                cx->group_cap = split ? (k + 1) / 2 : k / 2;
+                cx->group_cap = split ? (k + parts - 1) / parts : k / 2;
                 cx->fallbacks++;
                 continue;
             }
@@ -1523,22 +1552,21 @@ int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int
     if (gc.p.count == 0) return RTW_OK;
     RtwRenderParams t = gc.p; t.width = fb->width; t.height = fb->height;
     if (!choose_group_tiles(t, 0, fb->width * fb->height - 1)) return fail(RTW_ERR_LIMIT, "frame too large for the tile mapping");
-    size_t need0 = 0, need1 = 0;
+    size_t need[RTW_MAX_PARTS] = { 0, 0, 0, 0 };
     const int saved_cap = cx->group_cap;
     cx->group_cap = 0;
     for (int done = 0; done < n_passes;) {
-        bool split = false;
-        const int k = next_group(cx, gc.per_pass, n_passes - done, max_bounce, scene->texture_carry, false, &split);
-        const int kk = split ? k - k / 2 : k;
+        int parts = 1;
+        const int k = next_group(cx, gc.per_pass, n_passes - done, max_bounce, scene->texture_carry, false, &parts);
+        const int kk = (k + parts - 1) / parts;
         int ks = 0; while ((1 << ks) < kk) ks++;
         const size_t b = rtw::group_workspace_bytes((size_t)gc.per_pass << ks, max_bounce, scene->texture_carry, nullptr);
-        if (b > need0) need0 = b;
-        if (split && b > need1) need1 = b;
+        for (int j = 0; j < parts; j++) if (b > need[j]) need[j] = b;
         done += k;
     }
     cx->group_cap = saved_cap;
-    cx->lane = 0; rc = ensure_group_workspace(cx, need0);
-    if (rc == RTW_OK && need1 > 0) { cx->lane = 1; rc = ensure_group_workspace(cx, need1); cx->lane = 0; }
+    for (int j = 0; j < RTW_MAX_PARTS && rc == RTW_OK; j++) if (need[j] > 0) { cx->lane = j; rc = ensure_group_workspace(cx, need[j]); }
+    cx->lane = 0;
     if (rc != RTW_OK && cx->ws_refused) { cx->ws_refused = false; return RTW_OK; }      // not an error: the call will form smaller groups
     return rc;
 }
@@ -1548,13 +1576,15 @@ int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int
 long long rtw_context_memory_bytes(const rtw_context* ctx)
 {
     if (!ctx) return 0;
-    return (long long)(ctx->group_ws_bytes + ctx->group_ws2_bytes + ctx->workspace_bytes + (size_t)RTW_TABLE_SIZE * 3 * sizeof(float) + 2 * 1024 + 64);
+    size_t g = 0; for (int j = 0; j < RTW_MAX_PARTS; j++) g += ctx->group_ws_bytes[j];
+    return (long long)(g + ctx->workspace_bytes + (size_t)RTW_TABLE_SIZE * 3 * sizeof(float) + 2 * 1024 + 64);
 }
 // ... of which workspace (grows with the largest group rendered so far; rtw_context_trim gives it back)
 long long rtw_context_workspace_bytes(const rtw_context* ctx)
 {
     if (!ctx) return 0;
-    return (long long)(ctx->group_ws_bytes + ctx->group_ws2_bytes + ctx->workspace_bytes);
+    size_t g = 0; for (int j = 0; j < RTW_MAX_PARTS; j++) g += ctx->group_ws_bytes[j];
+    return (long long)(g + ctx->workspace_bytes);
 }
 int rtw_context_trim(rtw_context* ctx)
 {
@@ -1562,9 +1592,10 @@ int rtw_context_trim(rtw_context* ctx)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->aux_stream) HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
-    if (ctx->stream2) HIP_TRY(hipStreamSynchronize(ctx->stream2));
-    if (ctx->d_group_ws) { (void)hipFree(ctx->d_group_ws); ctx->d_group_ws = nullptr; ctx->group_ws_bytes = 0; ctx->group_clean = false; }
-    if (ctx->d_group_ws2) { (void)hipFree(ctx->d_group_ws2); ctx->d_group_ws2 = nullptr; ctx->group_ws2_bytes = 0; ctx->group_clean2 = false; }
+    for (int j = 0; j < RTW_MAX_PARTS; j++) {
+        if (ctx->part_stream[j]) HIP_TRY(hipStreamSynchronize(ctx->part_stream[j]));
+        if (ctx->d_group_ws[j]) { (void)hipFree(ctx->d_group_ws[j]); ctx->d_group_ws[j] = nullptr; ctx->group_ws_bytes[j] = 0; ctx->group_clean[j] = false; }
+    }
     if (ctx->d_workspace) { (void)hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_bytes = 0; ctx->clean_ws = nullptr; }
     return RTW_OK;
 }
@@ -1756,6 +1787,42 @@ int rtw_gather_rows(rtw_comm* comm, rtw_framebuffer* fb, int task_rows, int mode
 }
 
 long long rtw_comm_messages(const rtw_comm* comm) { return comm ? comm->messages : 0; }
+
+// rank 0's *value to every rank of the communicator (one 4-byte message per peer, through the staging block); returns when it has arrived
+int rtw_comm_broadcast_int(rtw_comm* comm, int* value)
+{
+    if (!comm || !value) return fail(RTW_ERR_INVALID, "null argument");
+    if (comm->world == 1) return RTW_OK;
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(RTW_ERR_STATE, g_rccl.error);
+    HIP_TRY(hipSetDevice(comm->ctx->device));
+    hipStream_t st = comm->ctx->stream;
+    if (comm->stage_bytes < 256) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (comm->d_stage) { (void)hipFree(comm->d_stage); comm->d_stage = nullptr; comm->stage_bytes = 0; }
+        HIP_TRY(hipMalloc(&comm->d_stage, 256));
+        comm->stage_bytes = 256;
+    }
+    ncclResult_t r = ncclSuccess;
+    if (comm->rank == 0) {
+        HIP_TRY(hipMemcpyAsync(comm->d_stage, value, sizeof(int), hipMemcpyHostToDevice, st));
+        if ((r = a->GroupStart()) == ncclSuccess) {
+            for (int peer = 1; peer < comm->world && r == ncclSuccess; peer++) { r = a->Send(comm->d_stage, sizeof(int), ncclChar, peer, comm->comm, st); comm->messages++; }
+            const ncclResult_t e = a->GroupEnd();
+            if (r == ncclSuccess) r = e;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        r = a->Recv(comm->d_stage, sizeof(int), ncclChar, 0, comm->comm, st);
+        comm->messages++;
+        if (r == ncclSuccess) {
+            HIP_TRY(hipMemcpyAsync(value, comm->d_stage, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    if (r != ncclSuccess) return rccl_fail(a, r, "rtw_comm_broadcast_int");
+    return RTW_OK;
+}
 
 // ---- stats ------------------------------------------------------------------------------------------------------
 int rtw_stats_enable(rtw_context* ctx, int enabled)

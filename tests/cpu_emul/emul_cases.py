@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000}
+DEFAULTS = {"group_parts": 2, "workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 
@@ -97,6 +97,12 @@ def case_ragged(ctx):
 
 def case_setup_scene(ctx):
     frame_case(ctx, "SetupScene (fuzz, lead shapes)", SC.SCENES["default"](), 48, 48, 1, 4, 2, options=[("device_build", 0)], f64=True, pipelines=(4, 3))
+
+
+def case_setup_scene_lanes(ctx):
+    """the default scene's bounce rounds through the persistent ray-per-lane kernel (leading analytic shapes + one mesh), also with a small visit budget"""
+    frame_case(ctx, "SetupScene, ray per lane", SC.SCENES["default"](), 48, 48, 2, 5, 2, options=[("device_build", 0), ("wave_below", 0)], f64=True)
+    frame_case(ctx, "SetupScene, ray per lane, budget 24", SC.SCENES["default"](), 48, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 24)], f64=True)
 
 
 def case_quirk(ctx):
@@ -121,6 +127,9 @@ def case_trace_variants(ctx):
     frame_case(ctx, "ray-per-lane, persistent waves", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0)])
     frame_case(ctx, "ray-per-lane, budget 8 + overflow", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 8)])
     frame_case(ctx, "groups of 2 passes", m, 64, 48, 1, 4, 5, options=[("device_build", 0), ("group_max", 2)])
+    u = mesh("unitychan", SC.diffuse())
+    frame_case(ctx, "ray-per-lane, tree partly in LDS", u, 64, 64, 1, 3, 2, options=[("device_build", 0), ("wave_below", 0)])
+    frame_case(ctx, "... and a budget of 40 visits", u, 64, 64, 1, 3, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 40)])
 
 
 def case_split(ctx):
@@ -128,6 +137,8 @@ def case_split(ctx):
     o = [("device_build", 0), ("split_min", 2), ("split_paths", 0)]
     frame_case(ctx, "two halves: mirror", mesh("TorusKnot", SC.reflective()), 96, 54, 1, 4, 7, options=o)
     frame_case(ctx, "two halves: SetupScene", SC.SCENES["default"](), 48, 48, 1, 4, 4, options=o, f64=True)
+    frame_case(ctx, "three parts, uneven", mesh("TorusKnot", SC.reflective()), 96, 54, 2, 4, 8, options=o + [("group_parts", 3)])
+    frame_case(ctx, "four parts", mesh("TorusKnot", SC.reflective()), 96, 54, 1, 4, 7, options=o + [("group_parts", 4)])
 
 
 def case_workspace(ctx):

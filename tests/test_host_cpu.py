@@ -295,7 +295,7 @@ def test_product_sources_under_address_and_ub_sanitizers():
     here, asan = _sanitizer_build()
     env = dict(os.environ, RTW_LIB=os.path.join(here, "_build", "librtwin_emul.so"), RTW_TEST_EMULATION="1", LD_PRELOAD=asan,
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    groups = [["device_build"], ["textured", "quirk", "setup_scene", "room", "tris"], ["mirror", "preview", "ragged", "shapes", "trace_variants", "queries", "split", "workspace"]]
+    groups = [["device_build"], ["textured", "quirk", "setup_scene", "setup_scene_lanes", "room", "tris"], ["mirror", "preview", "ragged", "shapes", "trace_variants", "queries", "split", "workspace"]]
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "emul_cases.py")] + g, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
              for g in groups]
     for g, p in zip(groups, procs):
