@@ -12,7 +12,9 @@
 
 #include "RayTracerWin.hpp"
 
-struct Seen { int frames; int titles; unsigned long long checksum; };
+#include <algorithm>
+#include <vector>
+struct Seen { int frames; int titles; unsigned long long checksum; std::vector<double> title_ms; };
 static void OnFrame(void* user, const Pixel* px, int w, int h)
 {
     Seen* s = (Seen*)user;
@@ -21,7 +23,12 @@ static void OnFrame(void* user, const Pixel* px, int w, int h)
     for (int i = 0; i < w * h; i++) sum += px[i] & 0xFFFFFFu;
     s->checksum = sum;
 }
-static void OnTitle(void* user, const char*) { ((Seen*)user)->titles++; }
+static void OnTitle(void* user, const char*)
+{
+    Seen* s = (Seen*)user;
+    s->titles++;
+    s->title_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
 // RTW_EXAMPLE_DEVICE_SINK=1: the window takes the image where it lies, in device memory (an interop surface / encoder would read it there): no host copy per present
 static void OnDeviceFrame(void* user, const void* device_pixels, int, int) { if (device_pixels) ((Seen*)user)->frames++; }
 
@@ -36,7 +43,7 @@ int main(int argc, char** argv)
         ColorBuffer Buffer(Device, W, H);
         // the display hook, as RayTracerProgram::Run sets its window up (Src/RayTracerProgram.cpp:445-455)
         std::vector<Pixel> Shown((size_t)W * H);
-        Seen seen = { 0, 0, 0ull };
+        Seen seen; seen.frames = 0; seen.titles = 0; seen.checksum = 0ull;
         RenderWindow Window;
         Window.Create(W, H);
         Window.SetRenderBufferParameters(W, H, Shown.data());
@@ -69,8 +76,13 @@ int main(int argc, char** argv)
         const std::chrono::steady_clock::time_point T0 = std::chrono::steady_clock::now();
         const std::string Saved = UpdateBitmapPixels(Device, Scene, Buffer, Run);
         const double TotalMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
-        if (Run.Rank == 0) std::printf("loop: %.3f ms for %d passes, %d per update: %.4f ms per update end to end (render + synchronise + title + present%s)\n", TotalMs, TotalSamplesNum,
-                                       Run.PassesPerUpdate, TotalMs / ((TotalSamplesNum + Run.PassesPerUpdate - 1) / Run.PassesPerUpdate + 1), DeviceSink ? " of the device image" : " through the host buffer");
+        if (Run.Rank == 0 && seen.title_ms.size() > 2) {     // the rhythm of the updates as the window saw them: time from one title to the next
+            std::vector<double> gaps;
+            for (size_t i = 1; i < seen.title_ms.size(); i++) gaps.push_back(seen.title_ms[i] - seen.title_ms[i - 1]);
+            std::sort(gaps.begin(), gaps.end());
+            std::printf("loop: %.3f ms for %d passes, %d per update; %.4f ms per update end to end, median over %d updates (render + synchronise + title + present%s)\n", TotalMs, TotalSamplesNum,
+                        Run.PassesPerUpdate, gaps[gaps.size() / 2], (int)gaps.size(), DeviceSink ? " of the device image" : " through the host buffer");
+        }
         if (Comm) RtwCheck(rtw_comm_destroy(Comm));
         if (Run.Rank != 0) return 0;
         Window.RunWindowLoop();

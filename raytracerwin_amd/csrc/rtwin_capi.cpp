@@ -1470,6 +1470,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
             int parts = 1;
             const int k = next_group(cx, per_pass, n_passes - done, max_bounce, scene->texture_carry, use_base_color != 0, &parts);
             const bool split = parts > 1;
+            rc = RTW_OK;        // (a refused group of the previous round has been re-formed)
             const bool first = done == 0, last = done + k >= n_passes;
             cx->batch_pos = (first && last) ? 0 : (first ? 1 : (last ? 3 : 2));
             if (split) {

@@ -155,6 +155,10 @@ def case_workspace(ctx):
     before = ctx.fallbacks()
     frame_case(ctx, "7 passes under a 1 MB limit", m, 96, 54, 1, 4, 7, options=[("device_build", 0), ("workspace_limit_mb", 1), ("split_min", 64)])
     assert ctx.fallbacks() > before and ctx.workspace_bytes() <= 1 << 20, (ctx.fallbacks(), before, ctx.workspace_bytes())
+    # a refused SPLIT group re-formed into a smaller split group (the second round must not see the first one's refusal)
+    before = ctx.fallbacks()
+    frame_case(ctx, "7 passes, split, 1 MB limit", SC.SCENES["shapes"](), 192, 64, 1, 2, 7, options=[("device_build", 0), ("workspace_limit_mb", 1), ("group_max", 4), ("split_min", 2), ("split_paths", 0)])
+    assert ctx.fallbacks() > before
     # a reserve ahead of the call: the call itself then allocates nothing
     ctx.trim()
     s = product_scene(ctx, m)

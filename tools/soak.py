@@ -115,6 +115,8 @@ def run(seed_arg, cases, ctx=None, log=print, only=-1, pipelines=(0, 3, 4), keep
                 rng.random()
             s.close()
             continue
+        if os.environ.get("RTW_SOAK_VERBOSE"):
+            log("case", it, kind, W, H, "spp", spp, "d", depth, "prev", prev, "passes", npass, "world", world, "rows", rows, opts, gopts, flush=True)
         res = []
         for pl in pipelines:
             ctx.set_option("pipeline", pl)
