@@ -92,6 +92,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *   "wave_below" (80 000; x 5 for trees of more than 4 096 nodes) a trace round with fewer rays runs a wave per ray; "visit_budget" (384) one-mesh scenes:
  *                   a ray's node visits in the ray-per-lane kernel before it goes to the wave-per-ray one (a rare ray that walks a thousand nodes kept its
  *                   whole wave waiting), for trees with more than "budget_nodes" (0) nodes;
+ *   "backface_filter" (1) one-mesh scenes whose tree fits LDS: the persistent trace blocks also stage the triangles' planes and never note a leaf whose
+ *                   triangle faces away from the ray's origin (RRay::TestIntersectionWithTriangle's first rejection, which does not depend on the segment);
  *   "workspace_limit_mb" (0 = 24 GiB) a group's workspace may not exceed this: larger groups are re-formed smaller (see rtw_context_memory_bytes);
  *   "device_build" (1) tree, layouts and screen bins built on the device; "hint_period" (16) pipeline 3: the queue lengths that size the next launches
  *                   are read back every n-th pass; "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms). */

@@ -55,16 +55,19 @@ struct GroupTuning {
     int cu_count = 256;
     bool single_mesh = false;      // the scene is one mesh: the trace rounds run persistent waves that refill their lanes
     bool lead_mesh = false;        // ... or leading analytic shapes followed by ONE mesh (shape staged_shape), no texel inheritance: the same kernel, continuing the lead query
-    // a group rendered as several parts on as many streams (rtwin_capi.cpp: rtw_render_passes): part sky_part of sky_parts renders its share of the group's
-    // sky tiles for ALL the group's passes (sky_first_pass, sky_passes) on its own stream; its resolve kernel waits for the previous part's (resolve_after)
-    // and signals the next (resolve_done)
-    int sky_passes = 0, sky_first_pass = 0, sky_part = 0, sky_parts = 1; hipEvent_t resolve_after = nullptr, resolve_done = nullptr;
+    // a group rendered as several parts on as many streams (rtwin_capi.cpp: rtw_render_passes): the group's sky tiles are rendered for ALL its passes
+    // (sky_first_pass, sky_passes) by one launch enqueued ahead of the parts (sky_mode 2); a part's resolve kernel waits for the previous part's
+    // (resolve_after) and signals the next (resolve_done)
+    int sky_passes = 0, sky_first_pass = 0, sky_mode = 0; hipEvent_t resolve_after = nullptr, resolve_done = nullptr;       // sky_mode 0: a whole group (sky on aux_stream beside it), 1: a part of a split group (no sky tiles), 2: ONLY the sky tiles of a split group, all its passes
+    int sparse_budget = 0;                   // ... and in a round with fewer rays than the launch has lanes (0: the same)
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
     int trace_hint[32];                      // scenes with leading analytic shapes: how many rays of a round still went to the trace launch (previous group)
     bool skip_trace = false;                 // every shape is a leading analytic shape: the shading lanes do the whole query, no trace launches
     int overflow_hint[32];                   // how many rays that were in the previous group, per round (-1 = unknown)
     int wave_below = 0;                      // a trace round whose list (previous group's length) is shorter than this runs a wave per ray
     bool staged_all = false;                 // ... and that is the shape's whole tree
+    int staged_tris = 0;                     // triangles of the staged shape
+    bool staged_planes = false;              // ... and the triangles' planes are staged beside it (persistent kernel: back-facing leaves are never noted)
     int staged_shape = -1, staged_top = 0;   // the trace blocks stage the first staged_top tnodes records of this shape in LDS (-1: nothing staged)
     hipEvent_t* timing = nullptr;  // null, or 4 events: before the primary kernel, after it, after the bounce rounds, after resolve
 };
@@ -81,6 +84,7 @@ struct DeviceBuildOut {     // device memory, the caller's from here on (hipFree
 int device_build_mesh(const DeviceBuildIn& in, int top_budget, DeviceBuildOut* out, hipStream_t stream);
 int device_build_bins(const RtwNode* d_nodes, const RtwTri* d_tris, int n_nodes, int width, int height, int bin_w, int bin_h,
                       uint32_t** off_out, uint32_t** ent_out, uint32_t* h_off, int* has_bins, hipStream_t stream);
+#define RTW_PERSIST_CAND_BYTES (8 * 1024 * 4)   // candidate lists of a persistent trace block: RTW_GT_CAP_STAGED words x 1024 threads
 #define RTW_TNODES_TOP_BUDGET 3072 // records (32 B each) of a tree's upper levels a block of the ray-per-lane trace kernel stages in LDS: 96 KiB
 int launch_render(const RtwSceneDev* sc, void* accum, void* argb, void* ws, const RtwRenderParams& p, bool stats, hipStream_t stream);
 int launch_closest(const RtwSceneDev* sc, const float* rays, long long n, float* hits11, int* shape, int* tri, bool stats, hipStream_t stream);

@@ -803,7 +803,9 @@ __device__ __forceinline__ uint32_t gamma_channel(const float* __restrict__ thr,
 // guess of gamma_channel's k (quality affects speed only)
 __device__ __forceinline__ int gamma_guess(float c)
 {
-    int k = (int)(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 2.2f)) * 255.0f);
+    if (!(c > 0.0f)) return 0;          // (NaN too: no float-to-int conversion of a NaN)
+    if (c >= 1.0f) return 254;
+    const int k = (int)(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 2.2f)) * 255.0f);
     return k < 0 ? 0 : (k > 254 ? 254 : k);
 }
 // the largest k with thr[k] <= c, given the guess g in 0..254 and the two table entries around it
@@ -1394,6 +1396,16 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
 {
     const RtwRenderParams& p = g.rp;
     if (g.n_passes <= 0 || (g.n_busy <= 0 && g.n_sky <= 0)) return 0;
+    if (tune.sky_mode == 2) {       // only the sky tiles of a split group, all the group's passes
+        if (g.n_sky > 0) {
+            RtwGroupParams gs = g;
+            gs.first_pass = tune.sky_first_pass; gs.n_passes = tune.sky_passes;
+            int sgrid = (gs.n_sky + 3) / 4;
+            if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
+            hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, gs);
+        }
+        return (int)hipGetLastError();
+    }
     GroupLayout l;
     group_workspace_bytes(tune.capacity, p.max_bounce, tune.carry, &l);
     char* w = (char*)workspace;
@@ -1404,16 +1416,8 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     gb.capacity = (uint32_t)tune.capacity; gb.carry_on = tune.carry ? 1 : 0;
     if (!tune.counters_clean) { hipError_t e = hipMemsetAsync(gb.counters, 0, 256, stream); if (e != hipSuccess) return (int)e; }
     bool forked = false;
-    if (g.n_sky > 0 && tune.sky_parts > 1) {
-        // a part of a split group: its share of the sky tiles, all the group's passes, first kernel of this part's stream
-        const int s0 = (int)((long long)g.n_sky * tune.sky_part / tune.sky_parts), s1 = (int)((long long)g.n_sky * (tune.sky_part + 1) / tune.sky_parts);
-        if (s1 > s0) {
-            RtwGroupParams gs = g;
-            gs.sky_tiles = g.sky_tiles + s0; gs.n_sky = s1 - s0; gs.first_pass = tune.sky_first_pass; gs.n_passes = tune.sky_passes;
-            int sgrid = (gs.n_sky + 3) / 4;
-            if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
-            hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, gs);
-        }
+    if (tune.sky_mode == 1) {
+        // a part of a split group: the sky tiles are not its business
     } else if (g.n_sky > 0) {
         RtwGroupParams gs = g;
         hipStream_t ss = stream;
@@ -1490,20 +1494,23 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                     }
                 } else if ((tune.single_mesh || tune.lead_mesh) && tune.staged_top > 0) {
                     // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
-#define RTW_LAUNCH_GPL(NT_, CAP_, STG, LD, BLOCKS, DYN)                                                                                          \
+                    // a launch with fewer rays than lanes lasts as long as its longest ray: such a round gets the smaller budget (its long rays go to the wave-per-ray launch that follows)
+                    const int budget_r = (trace_hint >= 0 && trace_hint < tune.cu_count * 1024 && tune.sparse_budget > 0 && tune.sparse_budget < tune.visit_budget) ? tune.sparse_budget : tune.visit_budget;
+#define RTW_LAUNCH_GPL(NT_, CAP_, STG, LD, PL, BLOCKS, DYN)                                                                                      \
                     do {                                                                                                                        \
-                        if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG, LD>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget, tune.staged_shape); } \
-                        else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
-                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG, LD>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, tune.visit_budget, tune.staged_shape); } \
+                        if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG, LD, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<true, NT_, CAP_, STG, LD, PL>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, budget_r, tune.staged_shape); } \
+                        else { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<false, NT_, CAP_, STG, LD, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+                            hipLaunchKernelGGL((gtrace_persist_kernel<false, NT_, CAP_, STG, LD, PL>), dim3(BLOCKS), dim3(NT_), (DYN), stream, sc, gb, r - 1, budget_r, tune.staged_shape); } \
                     } while (0)
-#define RTW_LAUNCH_GP(NT_, CAP_, STG, BLOCKS, DYN) do { if (tune.lead_mesh) RTW_LAUNCH_GPL(NT_, CAP_, STG, true, BLOCKS, DYN); else RTW_LAUNCH_GPL(NT_, CAP_, STG, false, BLOCKS, DYN); } while (0)
+#define RTW_LAUNCH_GP(NT_, CAP_, STG, PL, BLOCKS, DYN) do { if (tune.lead_mesh) RTW_LAUNCH_GPL(NT_, CAP_, STG, true, PL, BLOCKS, DYN); else RTW_LAUNCH_GPL(NT_, CAP_, STG, false, PL, BLOCKS, DYN); } while (0)
                     {
                         unsigned sbl = (tb + 3) / 4;
                         if (sbl > (unsigned)tune.cu_count) sbl = (unsigned)tune.cu_count;
                         const size_t dyn = (size_t)RTW_GT_CAP_STAGED * 1024 * 4 + (size_t)tune.staged_top * 32;
-                        if (tune.staged_all) RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 2, sbl, dyn);
-                        else RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 1, sbl, dyn);
+                        if (tune.staged_all && tune.staged_planes) RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 2, true, sbl, dyn + (size_t)tune.staged_tris * 16);
+                        else if (tune.staged_all) RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 2, false, sbl, dyn);
+                        else RTW_LAUNCH_GP(1024, RTW_GT_CAP_STAGED, 1, false, sbl, dyn);
                     }
 #undef RTW_LAUNCH_GP
 #undef RTW_LAUNCH_GPL

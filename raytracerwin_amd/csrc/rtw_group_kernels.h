@@ -671,7 +671,10 @@ __device__ __forceinline__ uint32_t batch_entry(uint32_t batch, uint32_t n_batch
 // LEAD: the scene is `ms` leading spheres / planes / capsules / triangles followed by this ONE mesh (the reference's default scene): the lane that set
 // the segment up has tested the leading shapes (group_lead_query); the list is the rays that can still meet the mesh's box, their hit records hold the
 // query so far, and the mesh's hits are measured against the segment those shapes left.
-template <bool STATS, int NT, int CAP, int STAGE, bool LEAD>
+// PLANES (only with the whole tree in LDS): the triangles' planes are staged too, and a leaf whose triangle faces away from the ray's origin -- the first
+// rejection of RRay::TestIntersectionWithTriangle, d2 = N . O - N . p0 < 0 (Src/RRay.cpp:156-158), independent of the segment -- is not noted at all:
+// about half the leaves a ray meets on a closed mesh, so half the triangle iterations (whose lanes run a quarter full).
+template <bool STATS, int NT, int CAP, int STAGE, bool LEAD, bool PLANES>
 __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, int round, int budget, int ms)
 {
     HIP_DYNAMIC_SHARED(uint32_t, gt_dyn);                 // [CAP * NT candidate words | staged records]
@@ -696,6 +699,13 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         const float4* src4 = reinterpret_cast<const float4*>(sh.tnodes);
         for (int k = (int)threadIdx.x; k < ltop * 2; k += NT) dst[k] = gld4(src4, (size_t)k);
         lnodes = dst;
+    }
+    const float4* lplanes = nullptr;
+    if (PLANES) {
+        float4* dst = reinterpret_cast<float4*>(gt_dyn + CAP * NT) + (size_t)sh.tnodes_top * 2;
+        const float4* src4 = reinterpret_cast<const float4*>(sh.planes);
+        for (int k = (int)threadIdx.x; k < sh.n_tris; k += NT) dst[k] = gld4(src4, (size_t)k);
+        lplanes = dst;
     }
     __syncthreads();
     constexpr bool ALLDS = STAGE == 2;
@@ -807,7 +817,11 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     const bool hit = (tmax > tmin) & !(tmin > far_t) & !(tmax < neg_eps);
                     const bool leaf = link >= 0;
                     if (STATS) ct.boxes++;
-                    if (hit & leaf) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
+                    if (hit & leaf) {
+                        bool facing = true;
+                        if (PLANES) { const float4 pl = lld4(lplanes, link); facing = !(dot(mk(pl.x, pl.y, pl.z), r.o) - pl.w < 0); }       // triangle_test's own d2 < 0 rejection, on the same values
+                        if (facing) { lstu(cand, ncand * NT + tid, (uint32_t)link); ncand++; }
+                    }
                     i = (hit & !leaf) ? ~link : skip;
                     visits++;
                 }

@@ -74,6 +74,9 @@ struct RtwShapeDev {
     // A record is RtwPNode: the box as (min, max) PAIRS per axis, so that (pair - origin) * reciprocal is one packed subtract and one
     // packed multiply per axis (v_pk_add_f32 / v_pk_mul_f32: component-wise the reference's float operations).
     const struct RtwPNode* tnodes;
+    const float* planes;            // per leaf slot 4 floats: the triangle's face normal and plane offset (RtwTri nx, ny, nz, d1) on their own, 16 bytes a leaf: the
+                                    // ray-per-lane walk drops a leaf whose triangle faces away from the ray's origin (RRay::TestIntersectionWithTriangle's first
+                                    // rejection, Src/RRay.cpp:156-158, which does not depend on the segment) before it is ever noted; null: not built
     float bmin[3], bmax[3];         // RShape::Aabb (all `v` lines)
     int32_t n_nodes, n_tris;
     int32_t n_textures;             // size of the reference's Textures vector (= triangle count when an MTL exists)

@@ -121,9 +121,12 @@ struct rtw_context {
     bool group_clean[RTW_MAX_PARTS] = { false, false, false, false };
     hipStream_t part_stream[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };        // [0] unused: part 0 runs on `stream`
     hipEvent_t split_fork = nullptr, part_resolved[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr }, part_done[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };
+    int sparse_budget = 0;                    // option: the visit budget of a trace round with fewer rays than lanes (0 = visit_budget)
+    int backface_filter = 1;                  // option: the persistent trace kernel stages the triangles' planes and never notes a leaf that faces away
     int group_parts = 2;                      // option: parts a split group runs as, at most (measured on C2 / C4 at 20 passes: 2 parts -8 % / -1 % against one, 3 and 4 parts +10..25 %)
     int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes ...
     int split_paths = 400000;                 // ... and each half at least this many paths (a rank's share of a small frame at 8 ranks stays whole: measured 0.0123 whole, 0.0144 ms split)
+    bool lane_sky_only = false;
     int lane = 0, lane_count = 1, lane_sky_passes = 0, lane_sky_first = 0;        // set by rtw_render_passes around render_group: which part of how many; the whole group's passes (the parts share out its sky tiles)
     uint32_t* h_gcounters = nullptr;    // pinned: list lengths of a finished group
     hipEvent_t gcounters_event = nullptr;
@@ -316,6 +319,8 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "workspace_limit_mb") == 0) { ctx->workspace_limit = value <= 0 ? ((size_t)24 << 30) : ((size_t)value << 20); return RTW_OK; }
+    if (std::strcmp(name, "sparse_budget") == 0) { ctx->sparse_budget = value < 0 ? 0 : value; return RTW_OK; }
+    if (std::strcmp(name, "backface_filter") == 0) { ctx->backface_filter = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "group_parts") == 0) { ctx->group_parts = value < 1 ? 1 : (value > RTW_MAX_PARTS ? RTW_MAX_PARTS : value); return RTW_OK; }
     if (std::strcmp(name, "group_split") == 0) { ctx->group_split = value != 0; return RTW_OK; }
     if (std::strcmp(name, "split_paths") == 0) { ctx->split_paths = value < 0 ? 0 : value; return RTW_OK; }
@@ -648,6 +653,11 @@ int rtw_scene_commit(rtw_scene* scene)
             }
             if ((rc = upload(scene, m.tris, &d.tris)) != RTW_OK) return rc;
             if ((rc = upload(scene, m.shade, &d.shade)) != RTW_OK) return rc;
+        }
+        if (m.kind == RTW_SHAPE_MESH && !m.tris.empty()) {      // the triangles' planes on their own (see RtwShapeDev::planes)
+            std::vector<float> planes(m.tris.size() * 4);
+            for (size_t t = 0; t < m.tris.size(); t++) { planes[t * 4] = m.tris[t].nx; planes[t * 4 + 1] = m.tris[t].ny; planes[t * 4 + 2] = m.tris[t].nz; planes[t * 4 + 3] = m.tris[t].d1; }
+            if ((rc = upload(scene, planes, &d.planes)) != RTW_OK) return rc;
         }
         COMMIT_MARK("layouts + uploads");
         std::vector<uint32_t> atlas;
@@ -1271,9 +1281,9 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.gamma_thr = cx->d_gamma;
     tune.has_analytic = scene->has_analytic; tune.carry = carry;
     tune.counters_clean = cx->group_clean[cx->lane];
-    if (cx->lane_count > 1) {       // a part of a split group: its share of the group's sky tiles (all the group's passes) on its own stream; its resolve kernel after the previous part's
+    if (cx->lane_count > 1) {       // a part of a split group: no sky tiles (the group's sky kernel was enqueued ahead of the parts, see rtw_render_passes); its resolve kernel after the previous part's
         tune.sky_passes = cx->lane_sky_passes; tune.sky_first_pass = cx->lane_sky_first;
-        tune.sky_part = cx->lane; tune.sky_parts = cx->lane_count;
+        tune.sky_mode = cx->lane_sky_only ? 2 : 1;
         tune.aux_stream = nullptr;
         tune.resolve_after = cx->lane > 0 ? cx->part_resolved[cx->lane - 1] : nullptr;
         tune.resolve_done = cx->part_resolved[cx->lane];
@@ -1283,10 +1293,16 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
         for (size_t k = 0; k < scene->meshes.size(); k++)
             if (scene->meshes[k]->kind == RTW_SHAPE_MESH && scene->meshes[k]->tnodes_top > 0) { tune.staged_shape = (int)k; tune.staged_top = scene->meshes[k]->tnodes_top; tune.staged_all = tune.staged_top == (int)scene->meshes[k]->tnodes.size(); break; }
     }
+    if (tune.staged_shape >= 0 && tune.staged_all) {        // ... and the triangles' planes beside a tree that lives in LDS entirely, if they fit (1 024-thread block: 32 KiB of candidate lists)
+        const size_t need = (size_t)RTW_PERSIST_CAND_BYTES + (size_t)tune.staged_top * 32 + scene->meshes[(size_t)tune.staged_shape]->tris.size() * 16;
+        tune.staged_planes = cx->backface_filter != 0 && need <= (size_t)150 * 1024;
+        tune.staged_tris = (int)scene->meshes[(size_t)tune.staged_shape]->tris.size();
+    }
     tune.single_mesh = scene->meshes.size() == 1 && scene->meshes[0]->kind == RTW_SHAPE_MESH && !scene->meshes[0]->nodes.empty();
     tune.lead_mesh = !carry && p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size() - 1 && scene->meshes.back()->kind == RTW_SHAPE_MESH && !scene->meshes.back()->nodes.empty() &&
                      tune.staged_shape == p.lead_shapes;
 
+    tune.sparse_budget = cx->sparse_budget;
     // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
     tune.visit_budget = (cx->visit_budget > 0 && (tune.single_mesh || tune.lead_mesh) && scene->meshes.back()->nodes.size() > (size_t)cx->budget_nodes) ? cx->visit_budget : INT32_MAX;
     {   // long walks (a tree of more than 4 096 nodes): the wave-per-ray kernel pays up to longer lists
@@ -1313,10 +1329,12 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     for (int r = 0; r < 16; r++) tune.trace_hint[r] = (cx->known_gkey == key) ? scaled(cx->known_gtrace[r]) : -1;
     tune.skip_trace = p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size();
     bool& clean = cx->group_clean[cx->lane];
-    clean = false;
+    const bool sky_only = tune.sky_mode == 2;       // (touches neither the workspace nor its counters)
+    if (!sky_only) clean = false;
     const hipError_t e = (hipError_t)rtw::launch_render_group(scene->d_scene, fb->accum, fb->argb, cx->d_group_ws[cx->lane], g, tune, cx->stats_enabled,
                                                               cx->lane ? cx->part_stream[cx->lane] : cx->stream);
     if (e != hipSuccess) return hip_fail(e, "group launch");
+    if (sky_only) return RTW_OK;
     clean = true;
     cx->last_pipeline = 4;
     cx->last_group_passes = cx->lane_count > 1 ? cx->lane_sky_passes : n_passes;
@@ -1490,6 +1508,11 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                     for (int j = 1; j < parts; j++) (void)hipStreamWaitEvent(cx->part_stream[j], cx->split_fork, 0);
                     int off = 0;
                     cx->lane_count = parts; cx->lane_sky_passes = k; cx->lane_sky_first = first_pass + done;
+                    // the sky tiles of the whole group (all k passes of their pixels in a row) FIRST, on the LAST part's stream: that part's chain is enqueued
+                    // last anyway (about 100 us of host time after the first part's), so the sky kernel runs where nothing else would yet
+                    cx->lane = parts - 1; cx->lane_sky_only = true;
+                    rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, base, sub_samples, seed);
+                    cx->lane_sky_only = false;
                     for (int j = 0; j < parts && rc == RTW_OK; j++) {
                         const int kj = base + (j < rem ? 1 : 0);
                         cx->lane = j;

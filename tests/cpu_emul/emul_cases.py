@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"group_parts": 2, "workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000}
+DEFAULTS = {"backface_filter": 1, "group_parts": 2, "workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 
@@ -125,6 +125,7 @@ def case_trace_variants(ctx):
     m = mesh("TorusKnot", SC.reflective())
     frame_case(ctx, "wave-per-ray trace kernel", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 1 << 30)])
     frame_case(ctx, "ray-per-lane, persistent waves", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0)])
+    frame_case(ctx, "... without the back-face filter", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("backface_filter", 0)])
     frame_case(ctx, "ray-per-lane, budget 8 + overflow", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 8)])
     frame_case(ctx, "groups of 2 passes", m, 64, 48, 1, 4, 5, options=[("device_build", 0), ("group_max", 2)])
     u = mesh("unitychan", SC.diffuse())

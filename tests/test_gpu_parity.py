@@ -526,8 +526,8 @@ def test_a_run_of_passes_with_one_fork_and_join_equals_pass_by_pass_calls(ctx, m
 @pytest.mark.parametrize("mesh,W,H,ns,depth,world", [("TorusKnot", 1920, 1080, 1, 4, 1), ("unitychan", 640, 360, 4, 4, 2), ("BlenderMonkey", 333, 217, 3, 6, 3),
                                                      ("TorusKnot", 640, 360, 2, 1, 1), ("BlenderMonkey", 200, 64, 4, 0, 1)])
 def test_k_batched_passes_equal_pass_by_pass(ctx, mesh, W, H, ns, depth, world):
-    """rtw_render_passes renders its passes in groups of K that share one set of launches (K x the rays per launch); every pixel's
-    accumulate + ARGB resolve still runs once per pass in pass order.  For every group size, first pass and split into calls the
+    """rtw_render_passes renders its passes in groups of K that share one set of launches (K x the rays per launch); a pixel's pass colours
+    are added in pass order, its accumulator entry and ARGB word written once per group.  For every group size, first pass and split into calls the
     accumulator and the ARGB image are those of one rtw_render_tasks call per pass through the single kernel (pipeline 0)."""
     mat = R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5)
     s = gpu_scene(ctx, mesh, mat)
@@ -557,12 +557,13 @@ def test_k_batched_passes_equal_pass_by_pass(ctx, mesh, W, H, ns, depth, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,W,H,ns,depth,npass", [("mesh", 640, 360, 2, 4, 13), ("default_nofuzz", 400, 400, 4, 5, 8), ("quirk", 320, 180, 4, 4, 9)])
-def test_group_as_two_halves_on_two_streams(ctx, tag, W, H, ns, depth, npass):
-    """A group of passes runs as two halves on two streams (own workspaces; the sky kernel takes the passes of both halves, the second half's
-    resolve waits for the first's).  Forced here for small frames (split_min 2, split_paths 0; by default only groups of >= 8 passes with
-    >= 400 k paths per half are split): accumulator and ARGB image equal one call per pass through the single kernel, for one call and for the
-    same passes in two calls."""
+@pytest.mark.parametrize("tag,W,H,ns,depth,npass,parts", [("mesh", 640, 360, 2, 4, 13, 2), ("default_nofuzz", 400, 400, 4, 5, 8, 2), ("quirk", 320, 180, 4, 4, 9, 2),
+                                                          ("mesh", 640, 360, 2, 4, 13, 3), ("default_nofuzz", 400, 400, 4, 5, 11, 4)])
+def test_group_as_parts_on_several_streams(ctx, tag, W, H, ns, depth, npass, parts):
+    """A group of passes runs as two (option group_parts: up to four) parts on as many streams (own workspaces; the group's sky kernel, all its passes, is
+    enqueued ahead of the parts; a part's resolve waits for the previous part's).  Forced here for small frames (split_min 2, split_paths 0; by default only
+    groups of >= 8 passes with >= 400 k paths per part are split): accumulator and ARGB image equal one call per pass through the single kernel, for one call
+    and for the same passes in two calls."""
     if tag == "mesh":
         s = gpu_scene(ctx, "TorusKnot", R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5))
     else:
@@ -575,6 +576,7 @@ def test_group_as_two_halves_on_two_streams(ctx, tag, W, H, ns, depth, npass):
     ctx.set_option("pipeline", DEFAULT_PIPELINE)
     ctx.set_option("split_min", 2)
     ctx.set_option("split_paths", 0)
+    ctx.set_option("group_parts", parts)
     try:
         for calls in ((npass,), (5, npass - 5)):
             fb = R.Framebuffer(ctx, W, H)
@@ -588,6 +590,7 @@ def test_group_as_two_halves_on_two_streams(ctx, tag, W, H, ns, depth, npass):
     finally:
         ctx.set_option("split_min", 8)
         ctx.set_option("split_paths", 400000)
+        ctx.set_option("group_parts", 2)
 
 
 @pytest.mark.gpu

@@ -44,7 +44,7 @@ for rnd in range(rounds):          # the sets interleaved, twice: drift of the b
             ctx.synchronize()
             res[o].append((time.perf_counter() - t0) * 1e3 / K)
         for k, v in kv:     # back to the library's defaults for the next set
-            ctx.set_option(k, {"group_parts": 2, "group_split": 1, "split_paths": 400000, "split_min": 8, "visit_budget": 384, "wave_below": 80000,
+            ctx.set_option(k, {"backface_filter": 1, "group_parts": 2, "group_split": 1, "split_paths": 400000, "split_min": 8, "visit_budget": 384, "wave_below": 80000,
                                "group_max": 256}.get(k, 0))
 for o in sets:
     a = np.array(res[o])
