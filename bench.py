@@ -457,6 +457,19 @@ def measure(B, cfg, K, Wm, primary):
     if rank == 0:
         final_accum = accum.cpu().numpy().view(np.uint32).reshape(-1, 4).copy()
         final_argb = argb.cpu().numpy().view(np.uint32).copy()
+        # ---- untimed diagnostic (N = 1): the same call three more times, host clock around call + synchronise -- what a caller's loop sees from its second
+        # call on (the timed call above is the FIRST of its shape after a shorter warm-up call: launch-size hints scaled from it, clocks just back from idle)
+        repeat_ms_per_step = None
+        if world == 1:
+            reps = []
+            with torch.cuda.stream(stream):
+                for i in range(3):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    steps(K * (i + 1), K)
+                    torch.cuda.synchronize(dev)
+                    reps.append((time.perf_counter() - t0) * 1e3 / K)
+            repeat_ms_per_step = min(reps)
         # ---- untimed: the same K passes once more on this GPU alone, pass by pass through the single kernel (pipeline 0, one thread per pixel):
         # the timed buffers must hold exactly these bits (N = 1 and N > 1 alike)
         fb2 = R.Framebuffer(ctx, W, H)
@@ -487,7 +500,7 @@ def measure(B, cfg, K, Wm, primary):
                "gather_ms": gather_ms, "rays_per_frame": rays_total / K, "camera_Mrays_per_s": cam_total / elapsed / 1e6,
                "verified": verified, "data": data, "depth": depth, "W": W, "H": H, "spp": spp, "kind": kind, "mesh_path": mesh_path,
                "commit_ms": commit_ms, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "pipeline_run": ctx.last_pass_pipeline(),
-               "memory_bytes": memory_bytes, "group_passes": group_passes}
+               "memory_bytes": memory_bytes, "group_passes": group_passes, "repeat_ms_per_step": repeat_ms_per_step}
         if primary:
             st_run_pass = {k: v / K for k, v in st.items()}
             # reference-faithful visit counts (un-pruned DFS order: what KdNode::TestRayIntersection visits) of ONE pass
@@ -631,6 +644,8 @@ def main():
             "nontrivial_rays_note": "rays that meet a shape's culling box: camera rays by pixel-centre direction (%d of %d per pass) + all secondary rays" % (m["nontrivial_cam"], npix * spp),
             "rays_per_frame": m["rays_per_frame"],
             "verified_bit_identical_to_single_kernel_replay": m["verified"],
+            "repeat_call_ms_per_step": m["repeat_ms_per_step"],
+            "repeat_call_note": "the timed call again, three more times (best; host clock around call + synchronise): the timed figure above is the first call of its shape after a shorter warm-up",
             "single_pass_ms": m["single"]["median"] if m["single"] else None,
             "single_pass_note": ("median of 20 separate rtw_render_passes(n = 1) calls (min %.4f, max %.4f ms; HIP events around each call; launch-size hints primed by 4 such calls): "
                                  "a frame that can be shown after EVERY pass, as the reference's window does" % (m["single"]["min"], m["single"]["max"])) if m["single"] else None,

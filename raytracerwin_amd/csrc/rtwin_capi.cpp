@@ -1589,7 +1589,15 @@ int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int
         done += k;
     }
     cx->group_cap = saved_cap;
-    for (int j = 0; j < RTW_MAX_PARTS && rc == RTW_OK; j++) if (need[j] > 0) { cx->lane = j; rc = ensure_group_workspace(cx, need[j]); }
+    for (int j = 0; j < RTW_MAX_PARTS && rc == RTW_OK; j++) if (need[j] > 0) {
+        cx->lane = j; rc = ensure_group_workspace(cx, need[j]);
+        // ... and the part's list counters zeroed on the part's own stream: its first group needs no memset, and a stream's first operation (the runtime
+        // sets its hardware queue up then) does not fall into a timed call
+        if (rc == RTW_OK && !cx->group_clean[j]) {
+            hipStream_t ps = j ? cx->part_stream[j] : cx->stream;
+            if (hipMemsetAsync(cx->d_group_ws[j], 0, 256, ps) == hipSuccess && hipStreamSynchronize(ps) == hipSuccess) cx->group_clean[j] = true;
+        }
+    }
     cx->lane = 0;
     if (rc != RTW_OK && cx->ws_refused) { cx->ws_refused = false; return RTW_OK; }      // not an error: the call will form smaller groups
     return rc;
