@@ -645,6 +645,7 @@ def main():
             "rays_per_frame": m["rays_per_frame"],
             "verified_bit_identical_to_single_kernel_replay": m["verified"],
             "repeat_call_ms_per_step": m["repeat_ms_per_step"],
+            "repeat_calls": 3 if m["repeat_ms_per_step"] else 0,
             "repeat_call_note": "the timed call again, three more times (best; host clock around call + synchronise): the timed figure above is the first call of its shape after a shorter warm-up",
             "single_pass_ms": m["single"]["median"] if m["single"] else None,
             "single_pass_note": ("median of 20 separate rtw_render_passes(n = 1) calls (min %.4f, max %.4f ms; HIP events around each call; launch-size hints primed by 4 such calls): "
