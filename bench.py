@@ -633,8 +633,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": m["data"],
             "config": {"workload": m["workload"],
                        "step": "one pass of the reference's sample loop over the whole frame; the K steps are ONE rtw_render_passes call, whose passes are rendered in groups "
-                               "that share one set of launches: every pixel's per-pass colour, accumulate, divide and gamma run once per pass in pass order, in registers; "
-                               "its accumulator entry and ARGB word are WRITTEN once per group -- intermediate images are not materialised inside a call (single_pass_ms is "
+                               "that share one set of launches: a pixel's pass colours are added to its accumulator one by one in pass order (in registers); its accumulator entry is written, and its "
+                               "ARGB word (divide + gamma of the accumulator after the group's last pass) computed and written, ONCE PER GROUP -- intermediate images are not materialised inside a call (single_pass_ms is "
                                "the rate at which a caller can show every pass)",
                        "sharding": "10-row tasks round-robin over ranks, one gather of the rows to rank 0 after the K passes",
                        "seed": SEED, "prune": args.prune, "pipeline": args.pipeline, "pipeline_run": m["pipeline_run"], "passes_per_group": group},

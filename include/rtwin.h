@@ -211,9 +211,10 @@ int rtw_render_tasks(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int r
                      int max_bounce, int use_base_color, int pass_index, int sub_samples, uint32_t seed);
 /* UpdateBitmapPixels' sample loop (Src/RayTracerProgram.cpp:317-361): n_passes accumulated passes
  * first_pass .. first_pass + n_passes - 1 over this rank's tasks, as rtw_render_tasks would render
- * them one by one (same final images).  The passes are rendered in groups that share one set of launches; a pixel's per-pass colour,
- * accumulate, divide and gamma run once per pass in pass order, its accumulator entry and ARGB word are written once per group:
- * intermediate images are not materialised inside a call (call it with n_passes = 1 to show every pass). */
+ * them one by one (same final images).  The passes are rendered in groups that share one set of launches; a pixel's pass colours are
+ * added to its accumulator one by one in pass order, its accumulator entry is written and its ARGB word (divide + gamma of the accumulator after
+ * the group's last pass) computed and written once per group: intermediate images are not materialised inside a call (call it with
+ * n_passes = 1 to show every pass). */
 int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int rank, int world,
                       int max_bounce, int use_base_color, int first_pass, int n_passes,
                       int sub_samples, uint32_t seed);
