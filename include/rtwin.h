@@ -86,7 +86,7 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   3 = one pass per set of launches: screen bins for the camera rays + one wave-per-ray trace launch and one shade launch per bounce
  *                   (the one-pass reference the pass-batched pipeline is compared with); 0 = one kernel, one thread per pixel (with
  *                   rtw_scene_set_traversal(0): the reference's own visit order, for the work counters).
- *   "group_max" (256) passes per group at most (a power of two), "group_paths" (16 Mi) paths a launch should hold; "group_split" (1) a group of at least
+ *   "group_max" (256) passes per group at most (a power of two), "group_paths" (32 Mi) paths a launch should hold; "group_split" (1) a group of at least
  *                   "split_min" (8) passes runs as up to "group_parts" (2; at most 4) parts of at least "split_paths" (400 000) paths each, on as many streams
  *                   (a workspace per part);
  *   "wave_below" (80 000; x 5 for trees of more than 4 096 nodes) a trace round with fewer rays runs a wave per ray; "visit_budget" (384) one-mesh scenes:

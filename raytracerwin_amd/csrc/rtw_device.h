@@ -40,6 +40,8 @@ int launch_render_pipeline(const RtwSceneDev* sc, void* accum, void* argb, void*
 // device address of the pipeline's counters inside the workspace (for the asynchronous read-back of the queue length)
 size_t pipeline_counters_offset(long long work_items, int max_bounce);
 // ---- pass-batched pipeline (pipeline 4, rtw_group_kernels.h) ----
+// slots of a group's workspace (rtw_group_kernels.h group_slot): one per path and pass
+inline size_t group_capacity(size_t paths_per_pass, int n_passes) { return paths_per_pass * (size_t)(n_passes > 0 ? n_passes : 1); }
 struct GroupLayout { size_t counters_off, rad_off, state_off, hit_off, carry_off, levels_off, list0_off, list1_off, overflow_off, tlist0_off, tlist1_off, total; };
 // device bytes of a group's workspace: `capacity` path slots (busy tiles x 64 x sub-samples x passes of the group, rounded up to a power of two of passes)
 size_t group_workspace_bytes(size_t capacity, int max_bounce, bool carry, GroupLayout* out);

@@ -688,10 +688,12 @@ __device__ __forceinline__ Bounce material_eval(const RtwSceneDev* __restrict__ 
 struct LevelStore {
     float4* __restrict__ ws; size_t stride; size_t tid;
     int rec_levels;     // 0: structure of arrays over the launch's threads (coalesced); > 0: one record of rec_levels x 3 float4 per
-                        // path slot (the slots of the per-bounce pipeline are sparse: a path's levels then share cache lines / pages)
+                        // path slot (the slots of the per-bounce pipeline are sparse: a path's levels then share cache lines / pages);
+                        // < 0: per level an array of 3 x float4 records over the slots (neighbouring slots neighbours, a record's 48 bytes together)
     __device__ __forceinline__ float4& at(int level, int j) const
     {
-        return rec_levels > 0 ? ws[(tid * (size_t)rec_levels + (size_t)level) * 3 + (size_t)j] : ws[((size_t)level * 3 + (size_t)j) * stride + tid];
+        return rec_levels > 0 ? ws[(tid * (size_t)rec_levels + (size_t)level) * 3 + (size_t)j]
+             : rec_levels < 0 ? ws[((size_t)level * stride + tid) * 3 + (size_t)j] : ws[((size_t)level * 3 + (size_t)j) * stride + tid];
     }
 };
 

@@ -42,7 +42,7 @@ struct GroupBufs {
     float4* __restrict__ state;     // [capacity * 3]  origin + distance | direction + draw counter | pixel, table reads, depth << 16 | levels, -
     float4* __restrict__ hit;       // [capacity * 2]  hit position + distance | shape, leaf slot or part, carry shape, carry slot
     float4* __restrict__ carry;     // [capacity]      texel-inheritance scenes: position of the mesh hit whose sampled colour the hit keeps
-    float4* __restrict__ levels;    // [capacity * max_bounce * 3]
+    float4* __restrict__ levels;    // [max_bounce][capacity][3]
     uint32_t* __restrict__ list0;   // ray lists (slots), ping-pong
     uint32_t* __restrict__ list1;
     uint32_t* __restrict__ tlist0;  // scenes whose first shapes are analytic (rp.lead_shapes > 0): the subset of a round's list whose query is not finished
@@ -53,10 +53,17 @@ struct GroupBufs {
     int32_t carry_on;               // the scene has an analytic shape after a textured mesh (Src/RRay.cpp:53-58,75-80: its hits keep the texel)
 };
 
+// A path's slot: lane-fastest -- the 64 paths of one (tile, sub-sample, pass) are neighbours and a tile's paths one compact region, so a wave that
+// works on paths in list order (the primary kernel's order, thinned by every round) reads and writes whole cache lines; exactly paths-per-pass x
+// passes slots.  The records stay one per slot (state 48 B, hit 32 B, a level 48 B): measured against the round-2 numbering (a pixel's passes
+// neighbours, lanes 16 x 48 B apart: C2 +5 %, C3 +8 %, C4 +6 %, C5 +6 %, SetupScene +17 % slower) and against structure-of-arrays records over the
+// same slots (a path's record then lies in three places: as slow as the round-2 numbering once the lists thin out).
 __device__ __forceinline__ uint32_t group_slot(const RtwGroupParams& g, uint32_t b, uint32_t lane, uint32_t sub, uint32_t k)
 {
-    return (((b * 64u + lane) * (uint32_t)g.rp.sub_samples + sub) << g.kshift) | k;
+    return ((b * (uint32_t)g.rp.sub_samples + sub) * (uint32_t)g.n_passes + k) * 64u + lane;
 }
+#define GST(gb_, slot_, j_) (gb_).state[(size_t)(slot_) * 3 + (j_)]
+#define GHT(gb_, slot_, j_) (gb_).hit[(size_t)(slot_) * 2 + (j_)]
 // pixel of (tile, lane); false: the lane has no pixel (past the frame's right / bottom edge, outside the rendered range)
 __device__ __forceinline__ bool group_xy(const RtwGroupParams& g, int wt, int lane, int& x, int& y)
 {
@@ -103,7 +110,7 @@ __device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__
 {
     const TravCtx tc = make_trav();
     if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
-    LevelStore lv; lv.ws = gb.levels; lv.stride = (size_t)gb.capacity; lv.tid = (size_t)slot; lv.rec_levels = p.max_bounce > 0 ? p.max_bounce : 1;
+    LevelStore lv; lv.ws = gb.levels; lv.stride = (size_t)gb.capacity; lv.tid = (size_t)slot; lv.rec_levels = -1;
     L = mk(0, 0, 0);
     bool done = false;
     const int hs = __float_as_int(r1.x), hslot = __float_as_int(r1.y);
@@ -192,12 +199,12 @@ __device__ __forceinline__ bool group_lead_query(const RtwSceneDev* __restrict__
     return more;
 }
 
-__device__ __forceinline__ void group_save_state(const GroupBufs& gb, uint32_t slot, const Ray& ray, const PathRng& rng, int depth, int nlev, int pixel)
+__device__ __forceinline__ void group_save_state(const GroupBufs& gb, uint32_t slot, const Ray& ray, const PathRng& rng, int depth, int nlev, int pixel, uint32_t pass_sub)
 {
-    gb.state[(size_t)slot * 3] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
-    gb.state[(size_t)slot * 3 + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
-    gb.state[(size_t)slot * 3 + 2] = make_float4(__int_as_float(pixel), __uint_as_float(rng.table_reads),
-                                                 __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), 0.0f);
+    GST(gb, slot, 0) = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.dist);
+    GST(gb, slot, 1) = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(rng.counter));
+    GST(gb, slot, 2) = make_float4(__int_as_float(pixel), __uint_as_float(rng.table_reads),
+                                                 __uint_as_float(((uint32_t)depth << 16) | (uint32_t)nlev), __uint_as_float(pass_sub));       // pass_sub: (pass in the group) << 2 | sub-sample
 }
 
 // ---- sky-only tiles: K passes per pixel with the accumulator entry in registers ----------------------------------------------
@@ -391,12 +398,12 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
                 Ray r = ray; PathRng rg = rng; int depth = p.max_bounce, nlev = 0;
                 f3 L;
                 if (group_shade_step<STATS, AN>(sc, p, gb, slot, r, rg, depth, nlev, hr0, hr1, hr2, L, ct)) {
-                    group_save_state(gb, slot, r, rg, depth, nlev, pixel);
+                    group_save_state(gb, slot, r, rg, depth, nlev, pixel, (kpass << 2) | (uint32_t)i);
                     queued |= 1u << i;
                     if (AN && p.lead_shapes > 0) {
                         float4 q0, q1;
                         if (group_lead_query<STATS>(sc, p.lead_shapes, r, q0, q1, ct)) tqueued |= 1u << i;
-                        gb.hit[(size_t)slot * 2] = q0; gb.hit[(size_t)slot * 2 + 1] = q1;
+                        GHT(gb, slot, 0) = q0; GHT(gb, slot, 1) = q1;
                     }
                 } else {
                     si = mk(0, 0, 0) + L;
@@ -617,18 +624,18 @@ __global__ __launch_bounds__(NT) void gtrace_kernel(const RtwSceneDev* __restric
         const uint32_t slot = have ? src[k] : 0u;
         Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.dist = 0.0f;
         if (have) {
-            const float4 s0 = gb.state[(size_t)slot * 3], s1 = gb.state[(size_t)slot * 3 + 1];
+            const float4 s0 = GST(gb, slot, 0), s1 = GST(gb, slot, 1);
             ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         }
         int hs = -1, hslot = -1, cs = -1, cslot = -1; f3 pos = mk(0, 0, 0), cpos = mk(0, 0, 0); float seg = ray.dist, cdist = 0.0f;
         if (AN && lead > 0 && have) {        // continue the query from what the shading lane found among the leading shapes
-            const float4 h0 = gb.hit[(size_t)slot * 2], h1 = gb.hit[(size_t)slot * 2 + 1];
+            const float4 h0 = GHT(gb, slot, 0), h1 = GHT(gb, slot, 1);
             pos = mk(h0.x, h0.y, h0.z); seg = h0.w; hs = __float_as_int(h1.x); hslot = __float_as_int(h1.y);
         }
         lane_find_intersection<STATS, AN, NT, CAP, (STAGE == 2)>(sc, cand, lnodes, ltop, STAGE ? staged_shape : -1, ray, have, AN ? lead : 0, hs, hslot, pos, seg, cs, cslot, cpos, cdist, ct);
         if (have) {
-            gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, seg);
-            gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(cs), __int_as_float(cslot));
+            GHT(gb, slot, 0) = make_float4(pos.x, pos.y, pos.z, seg);
+            GHT(gb, slot, 1) = make_float4(__int_as_float(hs), __int_as_float(hslot), __int_as_float(cs), __int_as_float(cslot));
             if (AN && gb.carry_on) gb.carry[slot] = make_float4(cpos.x, cpos.y, cpos.z, cdist);
         }
     }
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const uint32_t batch = DRAW ? j * gridDim.x + blockIdx.x : blockIdx.x * (uint32_t)(NT / 64) + j;
         const uint32_t k = batch_entry<SPREAD>(batch, n_batches, n, st_count);
-        if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
+        if (k < n) { st_slot = src[k]; st_s0 = GST(gb, st_slot, 0); st_s1 = GST(gb, st_slot, 1); }
     }
     RTW_TM(const unsigned long long tm_start = __builtin_amdgcn_s_memtime();)
     for (;;) {
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     eps_t = 2.0e-5f * fmaxf(fabsf(ix), fmaxf(fabsf(iy), fabsf(iz)));
                     cur = r.dist; pos = mk(0, 0, 0); leaf_out = -1; ncand = 0; visits = 0;
                     if (LEAD) {         // FindIntersectionWithScene so far (Src/RayTracerScene.cpp:99-125): the segment is already shortened by the leading shapes' hits
-                        const float4 h0 = gb.hit[(size_t)slot * 2], h1 = gb.hit[(size_t)slot * 2 + 1];
+                        const float4 h0 = GHT(gb, slot, 0), h1 = GHT(gb, slot, 1);
                         pos = mk(h0.x, h0.y, h0.z); cur = h0.w; lead_hs = __float_as_int(h1.x); lead_slot = __float_as_int(h1.y);
                     }
                     float t0, t1;       // the shape's culling box (Src/RayTracerScene.cpp:109)
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
                     }
                     st_used = 0u;
                     const uint32_t k = batch_entry<SPREAD>(batch, n_batches, n, st_count);
-                    if (k < n) { st_slot = src[k]; st_s0 = gb.state[(size_t)st_slot * 3]; st_s1 = gb.state[(size_t)st_slot * 3 + 1]; }
+                    if (k < n) { st_slot = src[k]; st_s0 = GST(gb, st_slot, 0); st_s1 = GST(gb, st_slot, 1); }
                 }
             }
         }
@@ -901,8 +908,8 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         // ---- lanes whose walk is complete: FindIntersectionWithScene's result for the one shape ----
         if (have & (i >= n_nodes)) {
             const int hs = leaf_out >= 0 ? (LEAD ? ms : 0) : (LEAD ? lead_hs : -1);
-            gb.hit[(size_t)slot * 2] = make_float4(pos.x, pos.y, pos.z, cur);
-            gb.hit[(size_t)slot * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(leaf_out >= 0 ? leaf_out : (LEAD ? lead_slot : -1)), __int_as_float(-1), __int_as_float(-1));
+            GHT(gb, slot, 0) = make_float4(pos.x, pos.y, pos.z, cur);
+            GHT(gb, slot, 1) = make_float4(__int_as_float(hs), __int_as_float(leaf_out >= 0 ? leaf_out : (LEAD ? lead_slot : -1)), __int_as_float(-1), __int_as_float(-1));
             have = false;
         }
         RTW_TM(tm_tri += __builtin_amdgcn_s_memtime() - tm_e2;)
@@ -941,17 +948,17 @@ __global__ __launch_bounds__(NT) void gtrace_wave_kernel(const RtwSceneDev* __re
     for (uint32_t k = wave; k < n; k += nwaves) {
         const int ku = __builtin_amdgcn_readfirstlane((int)k);
         const int q = (int)cldu(src, ku);
-        const float4 s0 = cld4(gb.state, q * 3), s1 = cld4(gb.state, q * 3 + 1);
+        const float4 s0 = GST(gb, q, 0), s1 = GST(gb, q, 1);
         Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
         int hs = -1, slot = -1; f3 pos = mk(0, 0, 0); float seg = ray.dist;
         if (AN && lead > 0) {
-            const float4 h0 = cld4(gb.hit, q * 2), h1 = cld4(gb.hit, q * 2 + 1);
+            const float4 h0 = GHT(gb, q, 0), h1 = GHT(gb, q, 1);
             pos = mk(h0.x, h0.y, h0.z); seg = h0.w; hs = __float_as_int(h1.x); slot = __float_as_int(h1.y);
         }
         wave_find_intersection<STATS, AN>(sc, AN ? lead : 0, n_shapes, prune, shape0, lds, ray, hs, slot, pos, seg, ct);
         if (lane_id() == 0) {
-            gb.hit[(size_t)q * 2] = make_float4(pos.x, pos.y, pos.z, seg);
-            gb.hit[(size_t)q * 2 + 1] = make_float4(__int_as_float(hs), __int_as_float(slot), __int_as_float(-1), __int_as_float(-1));
+            GHT(gb, q, 0) = make_float4(pos.x, pos.y, pos.z, seg);
+            GHT(gb, q, 1) = make_float4(__int_as_float(hs), __int_as_float(slot), __int_as_float(-1), __int_as_float(-1));
         }
     }
     if (STATS) flush_counters(sc, ct);
@@ -972,7 +979,6 @@ __global__ __launch_bounds__(256, RTW_GSHADE_MINB) void gshade_kernel(const RtwS
     const uint32_t nthreads = gridDim.x * blockDim.x;
     const int npix = p.width * p.height;
     const uint32_t phase = table_phase(p.seed);
-    const uint32_t kmask = (1u << g.kshift) - 1u;
     __shared__ uint32_t part[5];
     Counters ct = { 0, 0, 0, 0, 0, 0 };
     const uint32_t trips = (n + nthreads - 1) / nthreads;        // grid-uniform trip count: every thread joins the pushes
@@ -981,30 +987,28 @@ __global__ __launch_bounds__(256, RTW_GSHADE_MINB) void gshade_kernel(const RtwS
         const uint32_t slot = live ? src[k] : 0u;
         bool go_on = false, trace_on = false;
         if (live && slot < gb.capacity) {
-            const float4 s0 = gb.state[(size_t)slot * 3], s1 = gb.state[(size_t)slot * 3 + 1], s2 = gb.state[(size_t)slot * 3 + 2];
+            const float4 s0 = GST(gb, slot, 0), s1 = GST(gb, slot, 1), s2 = GST(gb, slot, 2);
             Ray ray; ray.o = mk(s0.x, s0.y, s0.z); ray.dist = s0.w; ray.d = mk(s1.x, s1.y, s1.z);
             const int pixel = __float_as_int(s2.x);
-            const uint32_t pass = (uint32_t)g.first_pass + (slot & kmask);
-            const uint32_t t = slot >> g.kshift;
-            uint32_t sub;
-            switch (p.sub_samples) { case 1: sub = 0u; break; case 2: sub = t & 1u; break; case 4: sub = t & 3u; break; default: sub = t - (t / 3u) * 3u; }
+            const uint32_t pass_sub = __float_as_uint(s2.w);
+            const uint32_t pass = (uint32_t)g.first_pass + (pass_sub >> 2), sub = pass_sub & 3u;
             PathRng rng;
             rng.key = stream_key(p.seed, (uint32_t)pixel, pass * 4u + sub);
             rng.counter = __float_as_uint(s1.w); rng.table_reads = __float_as_uint(s2.y);
             rng.table_base = (((uint64_t)pass * (uint64_t)npix + (uint64_t)pixel) * 4u + (uint64_t)sub) * RTW_TABLE_STRIDE + phase;
             rng.pre_reads = 0xFFFFFFFFu; rng.pre_x = rng.pre_y = rng.pre_z = 0.0f;
             int nlev = (int)(__float_as_uint(s2.z) & 0xFFFFu), depth = (int)(__float_as_uint(s2.z) >> 16);
-            const float4 r0 = gb.hit[(size_t)slot * 2], r1 = gb.hit[(size_t)slot * 2 + 1];
+            const float4 r0 = GHT(gb, slot, 0), r1 = GHT(gb, slot, 1);
             float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (AN && gb.carry_on) r2 = gb.carry[slot];
             f3 L;
             go_on = group_shade_step<STATS, AN>(sc, p, gb, slot, ray, rng, depth, nlev, r0, r1, r2, L, ct);
             if (go_on) {
-                group_save_state(gb, slot, ray, rng, depth, nlev, pixel);
+                group_save_state(gb, slot, ray, rng, depth, nlev, pixel, pass_sub);
                 if (AN && p.lead_shapes > 0) {
                     float4 q0, q1;
                     trace_on = group_lead_query<STATS>(sc, p.lead_shapes, ray, q0, q1, ct);
-                    gb.hit[(size_t)slot * 2] = q0; gb.hit[(size_t)slot * 2 + 1] = q1;
+                    GHT(gb, slot, 0) = q0; GHT(gb, slot, 1) = q1;
                 }
             } else { const f3 c = mk(0, 0, 0) + L; gb.rad[slot] = make_float4(c.x, c.y, c.z, 0.0f); }
         }

@@ -133,10 +133,10 @@ struct RtwBinsDev {
 
 // ---- pass-batched pipeline (pipeline 4): the passes first_pass .. first_pass + n_passes - 1 of one rtw_render_passes call share one
 // set of launches.  Tiles of the launch are either BUSY (some shape lists a leaf in the tile's bin, or has no bins) or SKY-ONLY.
-// A path's slot = (((b * 64 + lane) * sub_samples + sub) << kshift) | k   (b = rank of its tile in the busy list, k = pass - first_pass).
+// A path's slot = ((b * sub_samples + sub) * n_passes + k) * 64 + lane   (b = rank of its tile in the busy list, k = pass - first_pass).
 struct RtwGroupParams {
     RtwRenderParams rp;             // frame, tile mapping, bounce limit, seed, bins, camera tables (pass_index unused)
-    int32_t first_pass, n_passes, kshift;
+    int32_t first_pass, n_passes;
     int32_t n_busy, n_sky, n_jobs;
     const uint32_t* busy_tiles;     // tile numbers of the busy tiles, heaviest bins first; null: tile = first_tile + b (every tile of the range)
     const uint32_t* sky_tiles;      // tile numbers of the sky-only tiles

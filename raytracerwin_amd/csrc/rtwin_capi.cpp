@@ -141,7 +141,7 @@ struct rtw_context {
     int known_gtrace[16];
     int budget_nodes = 0;               // ... trees with more nodes than this get the budget
     int visit_budget = 384;             // one-mesh scenes: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
-    int group_paths = 16 << 20;         // passes are grouped until a launch holds about this many paths ...
+    int group_paths = 32 << 20;         // passes are grouped until a launch holds about this many paths (measured against 16 Mi: SetupScene -5 %, C5 at 20 passes -7 %, the others unchanged; 64 and 128 Mi: no further change) ...
     int group_max = 256;                // ... and at most this many passes (a power of two)
     int wave_below = 80000;             // a trace round with fewer rays (x 5 for trees of more than 4096 nodes) runs a wave per ray (measured with groups as two halves: C2 -3 % against 160 000; big trees keep 400 000)
     int device_build = 1;               // rtw_scene_commit builds the tree (KdNode::Build's decisions) and the layouts derived from it on the device (0: on the host)
@@ -1172,7 +1172,7 @@ static bool group_pipeline_ok(const rtw_scene* scene)
     return scene->ctx->pipeline == 4 && scene->traversal != 0;
 }
 
-// how many of the `remaining` passes the next group takes: enough for about group_paths paths per launch, a power of two of slots
+// how many of the `remaining` passes the next group takes: enough for about group_paths paths per launch
 static int group_passes(const rtw_context* cx, long long paths_per_pass, int remaining, int max_bounce, bool carry)
 {
     long long k = 1;
@@ -1246,8 +1246,6 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     p.bins = bs->d_bins; p.cam_dx = bs->d_dx; p.cam_dy = bs->d_dy;
     RtwGroupParams g; std::memset(&g, 0, sizeof g);
     g.first_pass = first_pass; g.n_passes = n_passes;
-    int kshift = 0; while ((1 << kshift) < n_passes) kshift++;
-    g.kshift = kshift;
     g.range_begin = range_begin; g.range_end = range_end; g.first_tile = 0;
     if (cx->stats_enabled) ranged = true;       // work counters: every camera ray goes through the primary kernel, which counts (the sky kernel does not)
     if (ranged) {           // every tile of the range is a job; the primary kernel finds out which see the sky only
@@ -1266,7 +1264,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     }
     g.rp = p;
     const bool carry = scene->texture_carry;
-    const size_t capacity = ((size_t)g.n_busy * 64 * (size_t)sub_samples) << kshift;
+    const size_t capacity = rtw::group_capacity((size_t)g.n_busy * 64 * (size_t)sub_samples, n_passes);
     if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");
     // the workspace of THIS group (grow-only): a caller that must not stall inside a later, longer call reserves it with rtw_render_reserve
     cx->ws_single = n_passes == 1 && cx->lane_count == 1;
@@ -1498,8 +1496,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                 // (first kernel of the part's stream); a part's resolve kernel waits for the previous part's, so a busy tile's passes are added in pass order.
                 const int base = k / parts, rem = k % parts;
                 {   // every part's workspace before anything of the group is launched: a refusal then leaves nothing half done
-                    int ks = 0; while ((1 << ks) < base + (rem ? 1 : 0)) ks++;
-                    const size_t need = rtw::group_workspace_bytes((size_t)per_pass << ks, max_bounce, scene->texture_carry, nullptr);
+                    const size_t need = rtw::group_workspace_bytes(rtw::group_capacity((size_t)per_pass, base + (rem ? 1 : 0)), max_bounce, scene->texture_carry, nullptr);
                     for (int j = 0; j < parts && rc == RTW_OK; j++) { cx->lane = j; rc = ensure_group_workspace(cx, need); }
                     cx->lane = 0;
                 }
@@ -1583,8 +1580,7 @@ int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int
         int parts = 1;
         const int k = next_group(cx, gc.per_pass, n_passes - done, max_bounce, scene->texture_carry, false, &parts);
         const int kk = (k + parts - 1) / parts;
-        int ks = 0; while ((1 << ks) < kk) ks++;
-        const size_t b = rtw::group_workspace_bytes((size_t)gc.per_pass << ks, max_bounce, scene->texture_carry, nullptr);
+        const size_t b = rtw::group_workspace_bytes(rtw::group_capacity((size_t)gc.per_pass, kk), max_bounce, scene->texture_carry, nullptr);
         for (int j = 0; j < parts; j++) if (b > need[j]) need[j] = b;
         done += k;
     }
