@@ -110,7 +110,12 @@ __device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__
 {
     const TravCtx tc = make_trav();
     if (!p.preview) prefetch_unit_vector(sc, rng);     // the table read (an HBM miss) overlaps the record loads below
-    LevelStore lv; lv.ws = gb.levels; lv.stride = (size_t)gb.capacity; lv.tid = (size_t)slot; lv.rec_levels = -1;
+#ifndef RTW_LEVEL_SKIP
+#define RTW_LEVEL_SKIP 1
+#endif
+    // a level's three fields lie in three arrays over the slots; a colour of exactly (1, 1, 1) and an emission of exactly (+0, +0, +0) are not stored
+    // (bits 2 and 3 of the kind word say so): x * 1 == x and the fold below still adds the zero, so the radiance has the same bits
+    LevelStore lv; lv.ws = gb.levels; lv.stride = (size_t)gb.capacity; lv.tid = (size_t)slot; lv.rec_levels = RTW_LEVEL_SKIP ? 0 : -1;
     L = mk(0, 0, 0);
     bool done = false;
     const int hs = __float_as_int(r1.x), hslot = __float_as_int(r1.y);
@@ -141,9 +146,17 @@ __device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__
                 const Bounce b = material_eval<false>(sc, sh, ray, h, out, rng);
                 if (rng.random() <= h.alpha) {
                     if (all_nonzero(b.att)) {
+#if RTW_LEVEL_SKIP
+                        const bool c1 = __float_as_uint(h.color.x) == 0x3F800000u && __float_as_uint(h.color.y) == 0x3F800000u && __float_as_uint(h.color.z) == 0x3F800000u;
+                        const bool e0 = (__float_as_uint(b.em.x) | __float_as_uint(b.em.y) | __float_as_uint(b.em.z)) == 0u;
+                        lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float((c1 ? 4 : 0) | (e0 ? 8 : 0)));
+                        if (!c1) lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
+                        if (!e0) lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+#else
                         lv.at(nlev, 0) = make_float4(b.att.x, b.att.y, b.att.z, __int_as_float(0));
                         lv.at(nlev, 1) = make_float4(h.color.x, h.color.y, h.color.z, 0.0f);
                         lv.at(nlev, 2) = make_float4(b.em.x, b.em.y, b.em.z, 0.0f);
+#endif
                         nlev++;
                         ray = out;
                     } else { L = mk(0, 0, 0) + b.em; done = true; }
@@ -160,8 +173,11 @@ __device__ __forceinline__ bool group_shade_step(const RtwSceneDev* __restrict__
     if (!done) return true;
     for (int kk = nlev - 1; kk >= 0; kk--) {
         const float4 a = lv.at(kk, 0);
-        if (__float_as_int(a.w) == 0) {
-            const float4 c = lv.at(kk, 1), e = lv.at(kk, 2);
+        const int kind = __float_as_int(a.w);
+        if ((kind & 3) == 0) {
+            float4 c = make_float4(1.0f, 1.0f, 1.0f, 0.0f), e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (!(kind & 4)) c = lv.at(kk, 1);
+            if (!(kind & 8)) e = lv.at(kk, 2);
             L = (mk(0, 0, 0) + (mk(a.x, a.y, a.z) * L) * mk(c.x, c.y, c.z)) + mk(e.x, e.y, e.z);
         } else {
             L = mk(0, 0, 0) + L;
