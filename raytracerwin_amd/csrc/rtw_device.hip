@@ -1439,7 +1439,8 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
     if (g.n_busy > 0) {
         const long long live_paths = (long long)g.n_busy * 64 * p.sub_samples * g.n_passes;
         {
-            const long long waves = (long long)g.n_jobs * g.n_passes;
+            const int ppw = (g.primary_passes > 1 && g.primary_passes * p.sub_samples <= 4) ? g.primary_passes : 1;        // as the kernel reads it
+            const long long waves = (long long)g.n_jobs * ((g.n_passes + ppw - 1) / ppw);
             const unsigned pgrid = (unsigned)((waves + 3) / 4);
             if (tune.has_analytic) {
                 if (stats) hipLaunchKernelGGL((gprimary_kernel<true, true>), dim3(pgrid), dim3(256), 0, stream, sc, gb, g);

@@ -262,9 +262,72 @@ __global__ __launch_bounds__(256) void gsky_kernel(const float* __restrict__ gam
 }
 
 // ---- camera rays of the busy tiles + first shading step -------------------------------------------------------------------------
+// The bins walk of one mesh for up to four camera rays per lane at once (the sub-samples of a pixel and / or the same pixel in several passes: they all start
+// at the camera and differ by their jitter only): an entry's leaf box and triangle record are fetched and broadcast once, every ray keeps its own
+// segment and meets the entries in the list's order (= preorder), so each ray's sequence of tests -- and every bit of its result -- is what it is
+// when the rays are walked one after the other.  All rays tame (the caller checks).
+template <bool STATS>
+__device__ __forceinline__ void bins_walk_rays(const RtwShapeDev& sh, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ bent, int bin, int lane, int nr, bool prune,
+                                               const f3 o, const f3 (&d)[4], const bool (&act)[4], float (&cur)[4], f3 (&pos)[4], int (&slot_hit)[4], bool (&any)[4], Counters& ct)
+{
+    float ix[4], iy[4], iz[4], eps_t[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        ix[r] = 1.0f / d[r].x; iy[r] = 1.0f / d[r].y; iz[r] = 1.0f / d[r].z;
+        eps_t[r] = 2.0e-5f * fmaxf(fabsf(ix[r]), fmaxf(fabsf(iy[r]), fabsf(iz[r])));
+    }
+    const int e0 = (int)cldu(boff, bin), e1 = (int)cldu(boff, bin + 1);
+    const float4* nd4 = reinterpret_cast<const float4*>(sh.nodes);
+    const float4* tr4 = reinterpret_cast<const float4*>(sh.tris);
+    for (int ec = e0; ec < e1; ec += 64) {
+        const int cnt = e1 - ec < 64 ? e1 - ec : 64;
+        const int mnode = lane < cnt ? (int)bent[ec + lane] : 0;
+        const float4 mlo = gld4(nd4, 2 * (size_t)mnode), mhi = gld4(nd4, 2 * (size_t)mnode + 1);
+        const int mleaf = __float_as_int(mhi.w) < 0 ? 0 : __float_as_int(mhi.w);
+        const float4 ta = gld4(tr4, 4 * (size_t)mleaf), tb = gld4(tr4, 4 * (size_t)mleaf + 1), tc = gld4(tr4, 4 * (size_t)mleaf + 2);
+        const float td = gld4(tr4, 4 * (size_t)mleaf + 3).x;
+        for (int j = 0; j < cnt; j++) {
+            const float lox = readlane_f(mlo.x, j), loy = readlane_f(mlo.y, j), loz = readlane_f(mlo.z, j);
+            const float hix = readlane_f(mhi.x, j), hiy = readlane_f(mhi.y, j), hiz = readlane_f(mhi.z, j);
+            const float ax = lox - o.x, bx = hix - o.x, ay = loy - o.y, by = hiy - o.y, az = loz - o.z, bz = hiz - o.z;
+            bool hit[4]; bool some = false;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                hit[r] = false;
+                if (r < nr) {
+                    const float x1 = ax * ix[r], x2 = bx * ix[r], y1 = ay * iy[r], y2 = by * iy[r], z1 = az * iz[r], z2 = bz * iz[r];
+                    const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+                    const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+                    bool h = act[r] && (tmax > tmin);
+                    if (prune) h = h && !(tmin > cur[r] + (eps_t[r] + 1.0e-4f * cur[r])) && !(tmax < -eps_t[r]);
+                    if (STATS) ct.boxes += act[r] ? 1u : 0u;
+                    hit[r] = h; some = some || h;
+                }
+            }
+            if (__ballot(some) == 0ull) continue;
+            const int leaf = __builtin_amdgcn_readlane(mleaf, j);
+            const float4 a = make_float4(readlane_f(ta.x, j), readlane_f(ta.y, j), readlane_f(ta.z, j), readlane_f(ta.w, j));
+            const float4 bq = make_float4(readlane_f(tb.x, j), readlane_f(tb.y, j), readlane_f(tb.z, j), readlane_f(tb.w, j));
+            const float4 c = make_float4(readlane_f(tc.x, j), readlane_f(tc.y, j), readlane_f(tc.z, j), readlane_f(tc.w, j));
+            const float d1 = readlane_f(td, j);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (r < nr && hit[r]) {
+                    if (STATS) ct.tris++;
+                    Ray rr; rr.o = o; rr.d = d[r]; rr.dist = cur[r];
+                    f3 cp; float dist;
+                    if (triangle_test(rr, cur[r], a, bq, c, d1, cp, dist)) { cur[r] = dist; pos[r] = cp; slot_hit[r] = leaf; any[r] = true; }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float pick4(int r, float a, float b, float c, float d) { return r == 0 ? a : (r == 1 ? b : (r == 2 ? c : d)); }
+
 template <bool STATS, bool AN>
 #ifndef RTW_GPRIMARY_MINB
-#define RTW_GPRIMARY_MINB 3      // measured in one session: 3 blocks of 256 per CU (<= 168 VGPRs) makes the primary kernel 13 % faster on unitychan (C4 0.343 -> 0.315 ms per pass), neutral on TorusKnot
+#define RTW_GPRIMARY_MINB 3      // measured in one session: 3 blocks of 256 per CU (<= 168 VGPRs) makes the primary kernel 13 % faster on unitychan (C4 0.343 -> 0.315 ms per pass), neutral on TorusKnot; 4 blocks (round 3, 128 VGPRs): C2 +3 %, C3 +4 % slower
 #endif
 __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const RtwSceneDev* __restrict__ sc, GroupBufs gb, RtwGroupParams g)
 {
@@ -274,18 +337,23 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
     const uint32_t phase = table_phase(p.seed);
     const int n_shapes = sc->n_shapes;
     const bool prune = sc->prune != 0;
-    const uint32_t total = (uint32_t)g.n_jobs * (uint32_t)g.n_passes;
+    // a wave takes `primary_passes` passes of its job (tile, or tile and sub-sample): at most four rays per lane
+    const uint32_t ppw = (g.primary_passes > 1 && g.primary_passes * p.sub_samples <= 4) ? (uint32_t)g.primary_passes : 1u;
+    const uint32_t wpj = ((uint32_t)g.n_passes + ppw - 1u) / ppw;
+    const uint32_t total = (uint32_t)g.n_jobs * wpj;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     __shared__ uint32_t part[5];
-    uint32_t q_out = 0u, tq_out = 0u, b_out = 0u, k_out = 0u;
+    uint32_t q_out = 0u, tq_out = 0u, b_out = 0u, k_out = 0u, s_out = 0u;
     if (wave < total) {
         // the passes of a tile are neighbouring waves (its bin list stays hot); jobs in the table's order, heaviest bins first
-        const uint32_t jidx = wave / (uint32_t)g.n_passes, kpass = wave - jidx * (uint32_t)g.n_passes;
+        const uint32_t jidx = wave / wpj, kbase = (wave - jidx * wpj) * ppw;
+        const uint32_t npw = (uint32_t)g.n_passes - kbase < ppw ? (uint32_t)g.n_passes - kbase : ppw;
         const uint32_t job = g.jobs ? cldu(g.jobs, (int)jidx) : jidx;
         const uint32_t b = job & 0xFFFFFFu;
         const int only_sample = (int)((job >> 24) & 15u) - 1;        // -1: this wave does every sub-sample of its tile
+        const uint32_t nsub = only_sample >= 0 ? 1u : (uint32_t)p.sub_samples;
+        const int nr = (int)(nsub * npw);                             // ray sets of this wave: r = (pass - kbase) * nsub + (index of the sub-sample)
         const int wt = g.busy_tiles ? (int)cldu(g.busy_tiles, (int)b) : g.first_tile + (int)b;
-        const int pass = g.first_pass + (int)kpass;
         const int lane = lane_id();
         int px = 0, py = 0;
         const bool live = group_xy(g, wt, lane, px, py);
@@ -304,9 +372,37 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
             const uint32_t* __restrict__ boff = p.bins[k].off;
             near_wave = near_wave || boff == nullptr || cldu(boff, bin) != cldu(boff, bin + 1);
         }
+        // ---- one mesh with bins and several ray sets: the bins walk once for all of them
+        float w_cur[4] = { 0.f, 0.f, 0.f, 0.f }; f3 w_pos[4]; int w_slot[4] = { -1, -1, -1, -1 }; bool w_any[4] = { false, false, false, false };
+#pragma unroll
+        for (int r = 0; r < 4; r++) w_pos[r] = mk(0, 0, 0);
+        bool shared_walk = false;
+        if (!AN && g.primary_passes > 0 && n_shapes == 1 && nr > 1 && nr <= 4 && near_wave && p.max_bounce != 0 && p.bins[0].off != nullptr) {
+            f3 w_d[4]; bool w_act[4]; bool all_tame = true;
+            const RtwShapeDev& sh = sc->shapes[0];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                w_d[r] = mk(0, 0, -1); w_act[r] = false;
+                if (r < nr) {
+                    const uint32_t po = (uint32_t)r / nsub, i = only_sample >= 0 ? (uint32_t)only_sample : (uint32_t)r - po * nsub;
+                    PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)g.first_pass + kbase + po, i);
+                    const Ray ray = camera_ray_xy(p, px, py, (int)i, rng);
+                    float t0, t1;
+                    w_d[r] = ray.d; w_cur[r] = ray.dist;
+                    w_act[r] = live && slab_exact(ray, sh.bmin[0], sh.bmin[1], sh.bmin[2], sh.bmax[0], sh.bmax[1], sh.bmax[2], t0, t1);
+                    all_tame = all_tame && (!live || ray_is_tame(ray));
+                }
+            }
+            if (__ballot(!all_tame) == 0ull) {
+                shared_walk = true;
+                bins_walk_rays<STATS>(sh, p.bins[0].off, p.bins[0].ent, bin, lane, nr, prune, mk(0, 0, 7.0f), w_d, w_act, w_cur, w_pos, w_slot, w_any, ct);
+            }
+        }
         uint32_t queued = 0u, tqueued = 0u;
-        for (int i = 0; i < p.sub_samples; i++) {                // wave-uniform loop
-            if (only_sample >= 0 && i != only_sample) continue;
+        for (int r = 0; r < nr; r++) {                           // wave-uniform loop
+            const uint32_t po = (uint32_t)r / nsub, kpass = kbase + po;
+            const int i = only_sample >= 0 ? only_sample : (int)((uint32_t)r - po * nsub);
+            const int pass = g.first_pass + (int)kpass;
             PathRng rng; rng_init(rng, p.seed, phase, (uint64_t)npix, (uint32_t)pixel, (uint32_t)pass, (uint32_t)i);
             const Ray ray = camera_ray_xy(p, px, py, i, rng);
             if (STATS && live) ct.cams++;
@@ -316,6 +412,19 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
             float4 hr0 = make_float4(0.f, 0.f, 0.f, 0.f), hr1 = hr0, hr2 = hr0;
             if (p.max_bounce != 0 && !near_wave && !STATS) {     // no leaf of any shape can be met from this tile: every sample sees the sky
                 if (live) si = sky_color(ray.d.y);
+            } else if (shared_walk) {                            // the walk above found this ray's closest hit
+                if (STATS && live) { ct.rays++; ct.boxes++; }
+                const bool any = r == 0 ? w_any[0] : (r == 1 ? w_any[1] : (r == 2 ? w_any[2] : w_any[3]));
+                if (live) {
+                    if (!any) si = sky_color(ray.d.y);
+                    else {
+                        have_hit = true;
+                        hr0 = make_float4(pick4(r, w_pos[0].x, w_pos[1].x, w_pos[2].x, w_pos[3].x), pick4(r, w_pos[0].y, w_pos[1].y, w_pos[2].y, w_pos[3].y),
+                                          pick4(r, w_pos[0].z, w_pos[1].z, w_pos[2].z, w_pos[3].z), pick4(r, w_cur[0], w_cur[1], w_cur[2], w_cur[3]));
+                        const int hslot = r == 0 ? w_slot[0] : (r == 1 ? w_slot[1] : (r == 2 ? w_slot[2] : w_slot[3]));
+                        hr1 = make_float4(__int_as_float(0), __int_as_float(hslot), __int_as_float(-1), __int_as_float(-1));
+                    }
+                }
             } else if (p.max_bounce != 0) {                      // RayTrace(.., 0) is black (Src/RayTracerScene.cpp:39)
                 // FindIntersectionWithScene of the camera ray (Src/RayTracerScene.cpp:99-125), shapes in insertion order
                 int hit_shape = -1, hit_slot = -1, carry_shape = -1, carry_slot = -1;
@@ -411,14 +520,14 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
                 }
             }
             if (have_hit) {                                      // shade the hit here: the path's slot needs no queue position
-                Ray r = ray; PathRng rg = rng; int depth = p.max_bounce, nlev = 0;
+                Ray rs = ray; PathRng rg = rng; int depth = p.max_bounce, nlev = 0;
                 f3 L;
-                if (group_shade_step<STATS, AN>(sc, p, gb, slot, r, rg, depth, nlev, hr0, hr1, hr2, L, ct)) {
-                    group_save_state(gb, slot, r, rg, depth, nlev, pixel, (kpass << 2) | (uint32_t)i);
-                    queued |= 1u << i;
+                if (group_shade_step<STATS, AN>(sc, p, gb, slot, rs, rg, depth, nlev, hr0, hr1, hr2, L, ct)) {
+                    group_save_state(gb, slot, rs, rg, depth, nlev, pixel, (kpass << 2) | (uint32_t)i);
+                    queued |= 1u << r;
                     if (AN && p.lead_shapes > 0) {
                         float4 q0, q1;
-                        if (group_lead_query<STATS>(sc, p.lead_shapes, r, q0, q1, ct)) tqueued |= 1u << i;
+                        if (group_lead_query<STATS>(sc, p.lead_shapes, rs, q0, q1, ct)) tqueued |= 1u << r;
                         GHT(gb, slot, 0) = q0; GHT(gb, slot, 1) = q1;
                     }
                 } else {
@@ -429,23 +538,24 @@ __global__ __launch_bounds__(256, RTW_GPRIMARY_MINB) void gprimary_kernel(const 
                 gb.rad[slot] = make_float4(si.x, si.y, si.z, 0.0f);
             }
         }
-        q_out = queued; tq_out = tqueued; b_out = b; k_out = kpass;
+        q_out = queued; tq_out = tqueued; b_out = b; k_out = kbase; s_out = (nsub << 8) | (uint32_t)(only_sample >= 0 ? only_sample : 0);
     }
     {
-        // ONE atomic per BLOCK: round 0's list gets an entry per sample that goes on (every wave of the block comes here, also one without a job)
-        const uint32_t queued = q_out, tqueued = tq_out, b = b_out, kpass = k_out;
+        // ONE atomic per BLOCK: round 0's list gets an entry per ray set that goes on (every wave of the block comes here, also one without a job)
+        const uint32_t queued = q_out, tqueued = tq_out, b = b_out, kbase = k_out, nsub = s_out >> 8 ? s_out >> 8 : 1u, sub0 = s_out & 255u;
         const int lane = lane_id();
         const unsigned long long m0 = __ballot((queued & 1u) != 0u), m1 = __ballot((queued & 2u) != 0u), m2 = __ballot((queued & 4u) != 0u),
                                  m3 = __ballot((queued & 8u) != 0u);
         const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
         const uint32_t qb = block_reserve<4>(&gb.counters[0], c0 + c1 + c2 + c3, part);
-        if (queued & 1u) gb.list0[qb + (uint32_t)mbcnt(m0)] = group_slot(g, b, (uint32_t)lane, 0u, kpass);
-        if (queued & 2u) gb.list0[qb + c0 + (uint32_t)mbcnt(m1)] = group_slot(g, b, (uint32_t)lane, 1u, kpass);
-        if (queued & 4u) gb.list0[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = group_slot(g, b, (uint32_t)lane, 2u, kpass);
-        if (queued & 8u) gb.list0[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = group_slot(g, b, (uint32_t)lane, 3u, kpass);
+        auto slot_of = [&](uint32_t r) { const uint32_t po = r / nsub; return group_slot(g, b, (uint32_t)lane, nsub == 1u ? sub0 : r - po * nsub, kbase + po); };
+        if (queued & 1u) gb.list0[qb + (uint32_t)mbcnt(m0)] = slot_of(0u);
+        if (queued & 2u) gb.list0[qb + c0 + (uint32_t)mbcnt(m1)] = slot_of(1u);
+        if (queued & 4u) gb.list0[qb + c0 + c1 + (uint32_t)mbcnt(m2)] = slot_of(2u);
+        if (queued & 8u) gb.list0[qb + c0 + c1 + c2 + (uint32_t)mbcnt(m3)] = slot_of(3u);
         if (AN && p.lead_shapes > 0) {       // the subset that still has to be traced
-            for (uint32_t i = 0; i < (uint32_t)p.sub_samples; i++)
-                block_push<4>(gb.tlist0, &gb.counters[24], (tqueued >> i) & 1u, group_slot(g, b, (uint32_t)lane, i, kpass), part);
+            for (uint32_t r = 0; r < 4u; r++)
+                block_push<4>(gb.tlist0, &gb.counters[24], (tqueued >> r) & 1u, slot_of(r), part);
         }
     }
     if (STATS) flush_counters(sc, ct);

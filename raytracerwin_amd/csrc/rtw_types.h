@@ -142,7 +142,8 @@ struct RtwGroupParams {
     const uint32_t* sky_tiles;      // tile numbers of the sky-only tiles
     const uint32_t* jobs;           // primary kernel: b | (sub-sample + 1) << 24 (0 in bits 24..27: every sub-sample); null: job = b
     int32_t range_begin, range_end; // inclusive pixel range that is rendered (a lane outside it is dead)
-    int32_t first_tile, pad0;
+    int32_t first_tile;
+    int32_t primary_passes;         // passes one wave of the primary kernel takes for its tile (> 1: x sub-samples <= 4; -1: one ray set at a time, no shared walk)
 };
 
 // random-stream constants (shared with the oracle by specification, not by code)

@@ -142,6 +142,7 @@ struct rtw_context {
     int budget_nodes = 0;               // ... trees with more nodes than this get the budget
     int visit_budget = 384;             // one-mesh scenes: node visits a ray gets in the ray-per-lane kernel before it goes to the wave-per-ray one (0: no limit)
     int group_paths = 32 << 20;         // passes are grouped until a launch holds about this many paths (measured against 16 Mi: SetupScene -5 %, C5 at 20 passes -7 %, the others unchanged; 64 and 128 Mi: no further change) ...
+    int primary_passes = 0;             // passes of a tile one wave of the primary kernel walks the tile's bin for at once (0: chosen per launch; -1: one ray set at a time, the round-2 order)
     int group_max = 256;                // ... and at most this many passes (a power of two)
     int wave_below = 80000;             // a trace round with fewer rays (x 5 for trees of more than 4096 nodes) runs a wave per ray (measured with groups as two halves: C2 -3 % against 160 000; big trees keep 400 000)
     int device_build = 1;               // rtw_scene_commit builds the tree (KdNode::Build's decisions) and the layouts derived from it on the device (0: on the host)
@@ -328,6 +329,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "budget_nodes") == 0) { ctx->budget_nodes = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "device_build") == 0) { ctx->device_build = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "primary_passes") == 0) { ctx->primary_passes = value < -1 ? -1 : (value > 4 ? 4 : value); return RTW_OK; }
     if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "group_max") == 0) {
         if (value < 1 || value > 256 || (value & (value - 1)) != 0) return fail(RTW_ERR_INVALID, "group_max must be a power of two in 1..256");
@@ -1263,6 +1265,16 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
         p.lead_shapes = lead;
     }
     g.rp = p;
+    // the primary kernel's waves: the bin of a tile is walked once for up to four rays per lane (its sub-samples and / or several passes) -- as many
+    // passes per wave as still leave the launch about two rounds of waves (C2 at 20 passes: 2 per wave 0.0367, 4 per wave 0.0376 ms per pass; at 192: 4 wins)
+    g.primary_passes = cx->primary_passes < 0 ? -1 : 1;        // -1: a ray set at a time (the round-2 kernel's order; kept for comparison)
+    if (cx->primary_passes >= 0 && !scene->has_analytic && scene->meshes.size() == 1) {
+        const int fit = 4 / sub_samples;
+        int ppw = cx->primary_passes > 0 ? (cx->primary_passes < fit ? cx->primary_passes : fit) : fit;
+        if (cx->primary_passes == 0)
+            while (ppw > 1 && (long long)g.n_jobs * ((n_passes + ppw - 1) / ppw) < (long long)cx->cu_count * 24) ppw >>= 1;
+        g.primary_passes = ppw < 1 ? 1 : ppw;
+    }
     const bool carry = scene->texture_carry;
     const size_t capacity = rtw::group_capacity((size_t)g.n_busy * 64 * (size_t)sub_samples, n_passes);
     if (capacity >= ((size_t)1 << 31)) return fail(RTW_ERR_LIMIT, "too many paths in one launch");

@@ -75,7 +75,7 @@ def frame_case(ctx, name, shapes, W, H, ns, depth, passes, preview=False, seed=1
     ctx.set_option("pipeline", 4)
 
 
-DEFAULTS = {"backface_filter": 1, "group_parts": 2, "workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000}
+DEFAULTS = {"backface_filter": 1, "group_parts": 2, "workspace_limit_mb": 0, "wave_below": 80000, "group_max": 256, "device_build": 1, "visit_budget": 384, "split_min": 8, "split_paths": 400000, "primary_passes": 0}
 mesh = lambda name, mat: [("mesh", name, mat)]  # noqa: E731
 
 
@@ -128,6 +128,10 @@ def case_trace_variants(ctx):
     frame_case(ctx, "... without the back-face filter", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("backface_filter", 0)])
     frame_case(ctx, "ray-per-lane, budget 8 + overflow", m, 64, 48, 1, 4, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 8)])
     frame_case(ctx, "groups of 2 passes", m, 64, 48, 1, 4, 5, options=[("device_build", 0), ("group_max", 2)])
+    # the primary kernel's shared bins walk: four passes of a tile per wave (7 passes: 4 + 3), two passes x two sub-samples, and the one-ray-set order
+    frame_case(ctx, "primary: 4 passes per wave", m, 64, 48, 1, 4, 7, options=[("device_build", 0), ("primary_passes", 4), ("split_min", 64)])
+    frame_case(ctx, "primary: 2 passes x 2 sub-samples", m, 64, 48, 2, 3, 3, options=[("device_build", 0), ("primary_passes", 2), ("split_min", 64)])
+    frame_case(ctx, "primary: one ray set at a time", m, 64, 48, 2, 3, 2, options=[("device_build", 0), ("primary_passes", -1)])
     u = mesh("unitychan", SC.diffuse())
     frame_case(ctx, "ray-per-lane, tree partly in LDS", u, 64, 64, 1, 3, 2, options=[("device_build", 0), ("wave_below", 0)])
     frame_case(ctx, "... and a budget of 40 visits", u, 64, 64, 1, 3, 2, options=[("device_build", 0), ("wave_below", 0), ("visit_budget", 40)])

@@ -70,7 +70,7 @@ def material(rng, depth=0):
     return R.SurfaceMaterial_Null()
 
 
-DEFAULTS = dict(pipeline=4, group_max=256, wave_below=80000, visit_budget=384, group_split=1, split_min=8, split_paths=400000, workspace_limit_mb=0)
+DEFAULTS = dict(pipeline=4, group_max=256, wave_below=80000, visit_budget=384, group_split=1, split_min=8, split_paths=400000, workspace_limit_mb=0, primary_passes=0)
 
 
 def run(seed_arg, cases, ctx=None, log=print, only=-1, pipelines=(0, 3, 4), keep=None, override=None):
@@ -107,7 +107,8 @@ def run(seed_arg, cases, ctx=None, log=print, only=-1, pipelines=(0, 3, 4), keep
         # the pass-batched pipeline's switches: passes per group, the wave-per-ray threshold, the visit budget, split groups, a workspace limit that forces smaller groups
         gopts = dict(group_max=int(rng.choice([1, 2, 4, 64, 256])), wave_below=int(rng.choice([0, 2000, 100000, 10000000])), visit_budget=int(rng.choice([0, 16, 384])),
                      group_split=int(rng.random() < 0.8), split_min=int(rng.choice([2, 2, 4, 8])), split_paths=int(rng.choice([0, 0, 400000])),
-                     workspace_limit_mb=int(rng.choice([0, 0, 0, 1, 8])))
+                     workspace_limit_mb=int(rng.choice([0, 0, 0, 1, 8])),
+                     primary_passes=[0, -1, 2, 4][(seed >> 3) & 3])       # (from the case's seed: no extra draw, so the cases of a soak seed stay what they were)
         if override:
             gopts.update(override)
         if only >= 0 and it != only:        # replay of one case: the others only advance the generator
