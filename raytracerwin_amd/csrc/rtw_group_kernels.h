@@ -1014,20 +1014,20 @@ __global__ __launch_bounds__(NT) void gtrace_persist_kernel(const RtwSceneDev* _
         {
             bool mine = 0 < ncand;
             int leaf = mine ? (int)lldu(cand, tid) : 0;
+            // (the record's d1 = dot(N, p0), by the same float operations on the device and on the host: computed here, one load a test less: C4 -1.5 %, C5 -0.8 %)
             float4 ta = gld4(tr4, 4 * (size_t)leaf), tb = gld4(tr4, 4 * (size_t)leaf + 1), tc = gld4(tr4, 4 * (size_t)leaf + 2);
-            float td = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)leaf + 12);
             for (int j = 0; __ballot(mine) != 0ull; j++) {
                 RTW_TM(tm_ttrips++; tm_tlanes += (uint32_t)__popcll(__ballot(mine));)
                 const bool nmine = j + 1 < ncand;
                 const int nleaf = nmine ? (int)lldu(cand, (j + 1) * NT + tid) : 0;
                 const float4 na = gld4(tr4, 4 * (size_t)nleaf), nb = gld4(tr4, 4 * (size_t)nleaf + 1), nc = gld4(tr4, 4 * (size_t)nleaf + 2);
-                const float nd = gld1(reinterpret_cast<const float*>(tr4), 16 * (size_t)nleaf + 12);
                 if (mine) {
                     if (STATS) ct.tris++;
                     f3 cp; float dist;
+                    const float td = dot(mk(ta.w, tb.w, tc.w), mk(ta.x, ta.y, ta.z));
                     if (triangle_test(r, cur, ta, tb, tc, td, cp, dist)) { cur = dist; pos = cp; leaf_out = leaf; }
                 }
-                mine = nmine; leaf = nleaf; ta = na; tb = nb; tc = nc; td = nd;
+                mine = nmine; leaf = nleaf; ta = na; tb = nb; tc = nc;
             }
             ncand = 0;
         }
