@@ -60,6 +60,7 @@ struct GroupTuning {
     // a group rendered as several parts on as many streams (rtwin_capi.cpp: rtw_render_passes): the group's sky tiles are rendered for ALL its passes
     // (sky_first_pass, sky_passes) by one launch enqueued ahead of the parts (sky_mode 2); a part's resolve kernel waits for the previous part's
     // (resolve_after) and signals the next (resolve_done)
+    int sky_blocks = 4;  // blocks of the sky kernel per CU at most (its lanes loop over the tiles)
     int sky_passes = 0, sky_first_pass = 0, sky_mode = 0; hipEvent_t resolve_after = nullptr, resolve_done = nullptr;       // sky_mode 0: a whole group (sky on aux_stream beside it), 1: a part of a split group (no sky tiles), 2: ONLY the sky tiles of a split group, all its passes
     int sparse_budget = 0;                   // ... and in a round with fewer rays than the launch has lanes (0: the same)
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows

@@ -1403,7 +1403,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
             RtwGroupParams gs = g;
             gs.first_pass = tune.sky_first_pass; gs.n_passes = tune.sky_passes;
             int sgrid = (gs.n_sky + 3) / 4;
-            if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
+            if (sgrid > tune.cu_count * tune.sky_blocks) sgrid = tune.cu_count * tune.sky_blocks;
             hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, stream, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, gs);
         }
         return (int)hipGetLastError();
@@ -1428,7 +1428,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
             if (forked) ss = tune.aux_stream;
         }
         int sgrid = (g.n_sky + 3) / 4;
-        if (sgrid > tune.cu_count * 16) sgrid = tune.cu_count * 16;
+        if (sgrid > tune.cu_count * tune.sky_blocks) sgrid = tune.cu_count * tune.sky_blocks;
         hipLaunchKernelGGL(gsky_kernel, dim3(sgrid), dim3(256), 0, ss, tune.gamma_thr, (float4*)accum, (uint32_t*)argb, gs);
         if (forked) {
             if (tune.do_join) (void)hipEventRecord(tune.join_event, tune.aux_stream);

@@ -127,6 +127,7 @@ struct rtw_context {
     int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes ...
     int split_paths = 400000;                 // ... and each half at least this many paths (a rank's share of a small frame at 8 ranks stays whole: measured 0.0123 whole, 0.0144 ms split)
     bool lane_sky_only = false;
+    int sky_blocks = 4;                 // the sky kernel's blocks per CU at most (its lanes loop over the tiles); 1, 2, 4, 16 measured: all within 1.5 % on C2 / C4, at 1 and 20 passes per call
     int lane = 0, lane_count = 1, lane_sky_passes = 0, lane_sky_first = 0;        // set by rtw_render_passes around render_group: which part of how many; the whole group's passes (the parts share out its sky tiles)
     uint32_t* h_gcounters = nullptr;    // pinned: list lengths of a finished group
     hipEvent_t gcounters_event = nullptr;
@@ -329,6 +330,7 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     if (std::strcmp(name, "budget_nodes") == 0) { ctx->budget_nodes = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "wave_below") == 0) { ctx->wave_below = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "device_build") == 0) { ctx->device_build = value ? 1 : 0; return RTW_OK; }
+    if (std::strcmp(name, "sky_blocks") == 0) { ctx->sky_blocks = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "primary_passes") == 0) { ctx->primary_passes = value < -1 ? -1 : (value > 4 ? 4 : value); return RTW_OK; }
     if (std::strcmp(name, "group_paths") == 0) { ctx->group_paths = value < 1 ? 1 : value; return RTW_OK; }
     if (std::strcmp(name, "group_max") == 0) {
@@ -1298,7 +1300,7 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
         tune.resolve_after = cx->lane > 0 ? cx->part_resolved[cx->lane - 1] : nullptr;
         tune.resolve_done = cx->part_resolved[cx->lane];
     }
-    tune.cu_count = cx->cu_count;
+    tune.cu_count = cx->cu_count; tune.sky_blocks = cx->sky_blocks;
     {      // the first mesh's upper tree levels live in the trace blocks' LDS
         for (size_t k = 0; k < scene->meshes.size(); k++)
             if (scene->meshes[k]->kind == RTW_SHAPE_MESH && scene->meshes[k]->tnodes_top > 0) { tune.staged_shape = (int)k; tune.staged_top = scene->meshes[k]->tnodes_top; tune.staged_all = tune.staged_top == (int)scene->meshes[k]->tnodes.size(); break; }
@@ -1518,7 +1520,9 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                     int off = 0;
                     cx->lane_count = parts; cx->lane_sky_passes = k; cx->lane_sky_first = first_pass + done;
                     // the sky tiles of the whole group (all k passes of their pixels in a row) FIRST, on the LAST part's stream: that part's chain is enqueued
-                    // last anyway (about 100 us of host time after the first part's), so the sky kernel runs where nothing else would yet
+                    // last anyway (about 100 us of host time after the first part's), so the sky kernel runs where nothing else would yet.  (Tried: the sky
+                    // kernel on a third, lowest-priority stream -- the last part's first kernel then still starts when the sky kernel ends (the two queues
+                    // share a dispatch pipe), C2 +4 %; every part's first kernel enqueued before any part's remaining launches: no change.)
                     cx->lane = parts - 1; cx->lane_sky_only = true;
                     rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, base, sub_samples, seed);
                     cx->lane_sky_only = false;
@@ -1533,6 +1537,7 @@ int rtw_render_passes(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int 
                         (void)hipEventRecord(cx->part_done[j], cx->part_stream[j]);
                         (void)hipStreamWaitEvent(cx->stream, cx->part_done[j], 0);
                     }
+
                 }
             } else
                 rc = render_group(scene, fb, p, false, 0, last_pixel, max_bounce, use_base_color, first_pass + done, k, sub_samples, seed);

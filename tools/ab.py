@@ -45,7 +45,7 @@ for rnd in range(rounds):          # the sets interleaved, twice: drift of the b
             res[o].append((time.perf_counter() - t0) * 1e3 / K)
         for k, v in kv:     # back to the library's defaults for the next set
             ctx.set_option(k, {"backface_filter": 1, "group_parts": 2, "group_split": 1, "split_paths": 400000, "split_min": 8, "visit_budget": 384, "wave_below": 80000,
-                               "group_max": 256, "primary_passes": 0, "group_paths": 32 << 20, "workspace_limit_mb": 24 << 10, "device_build": 1, "pipeline": 4}.get(k, 0))
+                               "group_max": 256, "primary_passes": 0, "sky_blocks": 4, "group_paths": 32 << 20, "workspace_limit_mb": 24 << 10, "device_build": 1, "pipeline": 4}.get(k, 0))
 for o in sets:
     a = np.array(res[o])
     print("%-4s K=%-3d %-60s median %.4f  min %.4f  (rounds %.4f / %.4f) ms per pass" % (cfg, K, o or "(defaults)", np.median(a), a.min(), np.median(a[:12]), np.median(a[12:])))
