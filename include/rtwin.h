@@ -94,6 +94,8 @@ int rtw_context_synchronize(rtw_context* ctx);
  *                   whole wave waiting), for trees with more than "budget_nodes" (0) nodes;
  *   "backface_filter" (1) one-mesh scenes whose tree fits LDS: the persistent trace blocks also stage the triangles' planes and never note a leaf whose
  *                   triangle faces away from the ray's origin (RRay::TestIntersectionWithTriangle's first rejection, which does not depend on the segment);
+ *   "primary_passes" (0 = chosen per launch; 1..4; -1 = one ray set at a time) one-mesh scenes: passes of a tile one wave of the primary kernel takes, its bin
+ *                   walked once for up to four rays per lane (sub-samples x passes <= 4); "sky_blocks" (4) blocks of the sky kernel per CU at most;
  *   "workspace_limit_mb" (0 = 24 GiB) a group's workspace may not exceed this: larger groups are re-formed smaller (see rtw_context_memory_bytes);
  *   "device_build" (1) tree, layouts and screen bins built on the device; "hint_period" (16) pipeline 3: the queue lengths that size the next launches
  *                   are read back every n-th pass; "kernel_timing" 1 = record events around the stages of each pass / group (rtw_last_pass_kernel_ms). */
@@ -226,8 +228,8 @@ int rtw_render_reserve(rtw_scene* scene, rtw_framebuffer* fb, int task_rows, int
                        int max_bounce, int n_passes, int sub_samples);
 /* Device memory the context holds: workspaces + its share of the 201 MB unit-vector table (one copy per device, shared by the contexts on it).
  * The workspace is sized by the largest group of passes rendered (or reserved) so far: per path slot 116 B + 48 B x max_bounce, slots = pixels of the
- * frame's busy tiles x sub-samples x passes per group (rounded up to a power of two); e.g. TorusKnot 1080p depth 4: 21 MB for one pass per call,
- * 0.68 GB for a 20-pass call.  When the device has no room for a group's workspace (or it exceeds the option "workspace_limit_mb"), the call renders
+ * frame's busy tiles x sub-samples x passes per group; e.g. TorusKnot 1080p depth 4: 21 MB for one pass per call,
+ * 0.43 GB for a 20-pass call.  When the device has no room for a group's workspace (or it exceeds the option "workspace_limit_mb"), the call renders
  * the same image in smaller groups instead of failing (rtw_context_fallbacks counts how often).  rtw_context_trim gives the workspaces back. */
 long long rtw_context_memory_bytes(const rtw_context* ctx);
 long long rtw_context_workspace_bytes(const rtw_context* ctx);

@@ -62,7 +62,6 @@ struct GroupTuning {
     // (resolve_after) and signals the next (resolve_done)
     int sky_blocks = 4;  // blocks of the sky kernel per CU at most (its lanes loop over the tiles)
     int sky_passes = 0, sky_first_pass = 0, sky_mode = 0; hipEvent_t resolve_after = nullptr, resolve_done = nullptr;       // sky_mode 0: a whole group (sky on aux_stream beside it), 1: a part of a split group (no sky tiles), 2: ONLY the sky tiles of a split group, all its passes
-    int sparse_budget = 0;                   // ... and in a round with fewer rays than the launch has lanes (0: the same)
     int visit_budget = INT32_MAX;            // persistent trace waves: a ray that needs more node visits than this is handed to a wave-per-ray launch that follows
     int trace_hint[32];                      // scenes with leading analytic shapes: how many rays of a round still went to the trace launch (previous group)
     bool skip_trace = false;                 // every shape is a leading analytic shape: the shading lanes do the whole query, no trace launches

@@ -1497,8 +1497,7 @@ int launch_render_group(const RtwSceneDev* sc, void* accum, void* argb, void* wo
                     }
                 } else if ((tune.single_mesh || tune.lead_mesh) && tune.staged_top > 0) {
                     // one mesh: persistent waves that refill their lanes (one block per CU when the tree's upper levels are staged)
-                    // a launch with fewer rays than lanes lasts as long as its longest ray: such a round gets the smaller budget (its long rays go to the wave-per-ray launch that follows)
-                    const int budget_r = (trace_hint >= 0 && trace_hint < tune.cu_count * 1024 && tune.sparse_budget > 0 && tune.sparse_budget < tune.visit_budget) ? tune.sparse_budget : tune.visit_budget;
+                    const int budget_r = tune.visit_budget;
 #define RTW_LAUNCH_GPL(NT_, CAP_, STG, LD, PL, BLOCKS, DYN)                                                                                      \
                     do {                                                                                                                        \
                         if (stats) { if ((DYN) > 65536) (void)hipFuncSetAttribute((const void*)gtrace_persist_kernel<true, NT_, CAP_, STG, LD, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \

@@ -121,7 +121,6 @@ struct rtw_context {
     bool group_clean[RTW_MAX_PARTS] = { false, false, false, false };
     hipStream_t part_stream[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };        // [0] unused: part 0 runs on `stream`
     hipEvent_t split_fork = nullptr, part_resolved[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr }, part_done[RTW_MAX_PARTS] = { nullptr, nullptr, nullptr, nullptr };
-    int sparse_budget = 0;                    // option: the visit budget of a trace round with fewer rays than lanes (0 = visit_budget)
     int backface_filter = 1;                  // option: the persistent trace kernel stages the triangles' planes and never notes a leaf that faces away
     int group_parts = 2;                      // option: parts a split group runs as, at most (measured on C2 / C4 at 20 passes: 2 parts -8 % / -1 % against one, 3 and 4 parts +10..25 %)
     int group_split = 1, split_min = 8;       // options: halves when a group has at least split_min passes ...
@@ -321,7 +320,6 @@ int rtw_context_set_option(rtw_context* ctx, const char* name, int value)
     }
     if (std::strcmp(name, "visit_budget") == 0) { ctx->visit_budget = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "workspace_limit_mb") == 0) { ctx->workspace_limit = value <= 0 ? ((size_t)24 << 30) : ((size_t)value << 20); return RTW_OK; }
-    if (std::strcmp(name, "sparse_budget") == 0) { ctx->sparse_budget = value < 0 ? 0 : value; return RTW_OK; }
     if (std::strcmp(name, "backface_filter") == 0) { ctx->backface_filter = value ? 1 : 0; return RTW_OK; }
     if (std::strcmp(name, "group_parts") == 0) { ctx->group_parts = value < 1 ? 1 : (value > RTW_MAX_PARTS ? RTW_MAX_PARTS : value); return RTW_OK; }
     if (std::strcmp(name, "group_split") == 0) { ctx->group_split = value != 0; return RTW_OK; }
@@ -1314,7 +1312,6 @@ static int render_group(rtw_scene* scene, rtw_framebuffer* fb, RtwRenderParams p
     tune.lead_mesh = !carry && p.lead_shapes > 0 && p.lead_shapes == (int)scene->meshes.size() - 1 && scene->meshes.back()->kind == RTW_SHAPE_MESH && !scene->meshes.back()->nodes.empty() &&
                      tune.staged_shape == p.lead_shapes;
 
-    tune.sparse_budget = cx->sparse_budget;
     // big trees: rays with very long walks (a few per cent need 4 x the mean) go to the wave-per-ray kernel instead of keeping a launch waiting
     tune.visit_budget = (cx->visit_budget > 0 && (tune.single_mesh || tune.lead_mesh) && scene->meshes.back()->nodes.size() > (size_t)cx->budget_nodes) ? cx->visit_budget : INT32_MAX;
     {   // long walks (a tree of more than 4 096 nodes): the wave-per-ray kernel pays up to longer lists
