@@ -427,6 +427,25 @@ def measure(B, cfg, K, Wm, primary):
             steps(2, Wm)
         if world > 1:
             gather()            # RCCL sets its channels up on first use; the staging blocks are allocated here
+        # ---- a frame that can be SHOWN after every pass (the reference's window blits bitcolor[] as the passes come, Src/RayTracerProgram.cpp:184-185,346-360):
+        # separate rtw_render_passes calls of ONE pass each, launch-size hints primed, each between two HIP events on the launch stream.  Measured HERE, ahead of
+        # the timed region, on every rank: a few milliseconds of the same kernels right before it.  (A stand-alone script with bench.py's sequence measured the
+        # first 20-pass call after the set-up at 0.043 - 0.045 ms per pass by HIP events, after 40 such one-pass calls at 0.038 - 0.042, the calls that follow at
+        # 0.037 - 0.039 either way; inside bench.py the one-shot figure still varies 0.039 - 0.044 from run to run -- see repeat_call_ms_per_step.)
+        single = None
+        if primary:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+            for i in range(4):
+                steps(Wm + 2 + i, 1)
+            torch.cuda.synchronize(dev)
+            for i in range(20):
+                evs[i].record(stream)
+                steps(Wm + 6 + i, 1)
+            evs[20].record(stream)
+            torch.cuda.synchronize(dev)
+            per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))
+            if world == 1:
+                single = {"median": per[10], "min": per[0], "max": per[-1], "calls": 20}
     B.barrier()
     accum.zero_()
     argb.zero_()
@@ -514,22 +533,6 @@ def measure(B, cfg, K, Wm, primary):
             scene.set_prune(args.prune)
             scene.set_traversal(1)
             ctx.stats_enable(False)
-            # ---- a frame that can be SHOWN after every pass (the reference's window blits bitcolor[] as the passes come, Src/RayTracerProgram.cpp:184-185,346-360):
-            # separate rtw_render_passes calls of ONE pass each, launch-size hints primed, each between two HIP events on the launch stream
-            single = None
-            if world == 1:
-                evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-                with torch.cuda.stream(stream):
-                    for i in range(4):
-                        scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, K + i, 1, spp, SEED)
-                    torch.cuda.synchronize(dev)
-                    for i in range(20):
-                        evs[i].record(stream)
-                        scene.render_passes(fb2, TASK_ROWS, 0, 1, depth, None, K + 4 + i, 1, spp, SEED)
-                    evs[20].record(stream)
-                torch.cuda.synchronize(dev)
-                per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))
-                single = {"median": per[10], "min": per[0], "max": per[-1], "calls": 20}
             # ---- per-stage durations: HIP events recorded by the library on the launch stream around the stages of one group (extra untimed passes)
             stage_ms = None
             if args.pipeline >= 3:
