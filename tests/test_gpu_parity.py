@@ -594,6 +594,33 @@ def test_group_as_parts_on_several_streams(ctx, tag, W, H, ns, depth, npass, par
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mesh,W,H,ns,depth,npass", [("TorusKnot", 1920, 1080, 1, 4, 11), ("unitychan", 640, 360, 2, 3, 5), ("BlenderMonkey", 501, 283, 4, 4, 3),
+                                                    ("BlenderMonkey", 333, 211, 3, 3, 4)])
+def test_primary_kernel_walks_a_bin_once_for_several_rays(ctx, mesh, W, H, ns, depth, npass):
+    """One-mesh scenes: a wave of the primary kernel takes up to four rays per lane through its tile's bin at once -- the pixel's sub-samples and / or the
+    same pixel in several passes (option primary_passes: 0 = chosen per launch, 1, 2, 4; -1 = one ray set at a time, the order every other kernel is
+    compared with).  Every setting gives the accumulator and the ARGB image of one call per pass through the single kernel (pass counts that do not
+    divide by the passes per wave, ragged frames, 1 - 4 sub-samples)."""
+    s = gpu_scene(ctx, mesh, R.SurfaceMaterial_Blend(R.SurfaceMaterial_Reflective((0.9, 0.9, 0.9), 0.0), R.SurfaceMaterial_Diffuse((1.0, 0.9, 0.8)), 0.5))
+    ctx.set_option("pipeline", 0)
+    ref = R.Framebuffer(ctx, W, H)
+    for p in range(npass):
+        R.ThreadWorker_Render(s, ref, 0, W * H - 1, depth, None, p, ns, 4242)
+    ra, rb = ref.read_float(), ref.resolve_argb()
+    ctx.set_option("pipeline", DEFAULT_PIPELINE)
+    try:
+        for pp in (0, -1, 1, 2, 4):
+            ctx.set_option("primary_passes", pp)
+            fb = R.Framebuffer(ctx, W, H)
+            s.render_passes(fb, 10, 0, 1, depth, None, 0, npass, ns, 4242)
+            assert ctx.last_pass_pipeline() == 4
+            assert (bits(fb.read_float()) == bits(ra)).all() and (fb.resolve_argb() == rb).all(), pp
+            fb.close()
+    finally:
+        ctx.set_option("primary_passes", 0)
+
+
+@pytest.mark.gpu
 def test_groups_of_more_than_64_passes(ctx):
     """The largest groups the default policy forms (256 passes: a rank's share of a frame at 8 ranks, small frames): 200 passes of a small frame
     in one group (8 bits of a slot hold the pass), against one call per pass through the single kernel."""
