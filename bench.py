@@ -455,7 +455,9 @@ def measure(B, cfg, K, Wm, primary):
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
+        t_enq = time.perf_counter()
         steps(0, K)
+        enqueue_ms = (time.perf_counter() - t_enq) * 1e3      # host time inside the one rtw_render_passes call (its launches are asynchronous)
         ev1.record(stream)
         if world > 1:
             gather()            # the one exchange of the path: every rank's rows to rank 0, once, after the K passes
@@ -515,7 +517,7 @@ def measure(B, cfg, K, Wm, primary):
                            "%s.obj %dx%d %d spp depth %d, %s, 1 mesh, reference camera (BASELINE configs[%s]%s)"
                            % (mesh, W, H, spp, depth, kind, {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[cfg],
                               "; a step is one 4-spp pass, four of them make the config's 16 spp" if cfg == "c5" else ""),
-               "value": rays_total / elapsed / 1e6, "steps": K, "warmup": Wm, "ms_per_step": ms_per_step, "render_ms_per_step_rank0": render_ms / K,
+               "value": rays_total / elapsed / 1e6, "steps": K, "warmup": Wm, "ms_per_step": ms_per_step, "render_ms_per_step_rank0": render_ms / K, "enqueue_ms": enqueue_ms,
                "gather_ms": gather_ms, "rays_per_frame": rays_total / K, "camera_Mrays_per_s": cam_total / elapsed / 1e6,
                "verified": verified, "data": data, "depth": depth, "W": W, "H": H, "spp": spp, "kind": kind, "mesh_path": mesh_path,
                "commit_ms": commit_ms, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "pipeline_run": ctx.last_pass_pipeline(),
@@ -649,6 +651,8 @@ def main():
             "verified_bit_identical_to_single_kernel_replay": m["verified"],
             "repeat_call_ms_per_step": m["repeat_ms_per_step"],
             "repeat_calls": 3 if m["repeat_ms_per_step"] else 0,
+            "timed_call_ms": {"wall_between_barriers": ms * K, "hip_events_around_the_call": m["render_ms_per_step_rank0"] * K, "host_inside_the_call": m["enqueue_ms"],
+                              "note": "the K steps are one asynchronous call: `host_inside_the_call` is how long the host took to enqueue its launches; a stall of that thread shows here and in both other figures"},
             "repeat_call_note": "the timed call again, three more times (best; host clock around call + synchronise): the timed figure above is the first call of its shape after a shorter warm-up",
             "single_pass_ms": m["single"]["median"] if m["single"] else None,
             "single_pass_note": ("median of 20 separate rtw_render_passes(n = 1) calls (min %.4f, max %.4f ms; HIP events around each call; launch-size hints primed by 4 such calls): "
