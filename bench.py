@@ -28,6 +28,7 @@ fraction is computed from `ms_per_step`.  `cpu_baseline` times the reference's C
 own sources) on the host cores.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -452,6 +453,8 @@ def measure(B, cfg, K, Wm, primary):
     B.barrier()
 
     ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    gc.collect()
+    gc.disable()        # (a collection of the interpreter's object graph -- parsed meshes, fixtures -- inside the timed region would stall the thread that enqueues the launches)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
@@ -464,6 +467,7 @@ def measure(B, cfg, K, Wm, primary):
         ev2.record(stream)
     B.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     render_ms = ev0.elapsed_time(ev1)               # HIP events on the launch stream around the K steps (this rank)
     gather_ms = ev1.elapsed_time(ev2) if world > 1 else None
     if world > 1:
