@@ -357,7 +357,7 @@ class Bench:
         self.torch.cuda.synchronize(self.dev)
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize(self.dev)
+            self.torch.cuda.synchronize(self.dev)
 
     def close(self):
         if self.world > 1:
